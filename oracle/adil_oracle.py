@@ -1,0 +1,664 @@
+"""ORACLE — test infrastructure, NOT product code.
+
+CPU (torch fp32) restatement of the reference's ADiL hot path, used only as the
+checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under dl_attack_on_imagenet_amd/ or attacks/ may import this module.
+
+Every function cites the reference file:line (relative to the upstream repo
+flavie-yuan-liu/DL_attack_on_ImageNet) it restates.  The arithmetic of the
+reference lives in PyTorch (tensordot, autograd, optim.AdamW, sort/cumsum,
+Softshrink, CrossEntropyLoss); this file restates it with explicit formulas
+so the kernels can be checked stage by stage, and is PINNED by the golden
+vectors under tests/golden/, which were produced by running the reference
+itself (tests/golden/make_golden.py) in the build container.
+
+Differences from the reference that do not change results:
+  * all random draws (D0, V0, batch order, sphere samples) are INJECTED instead
+    of being drawn from the global torch RNG, so GPU and CPU runs can share them;
+  * the frozen classifier's parameters are not differentiated (reference quirk
+    Q8: wasted weight grads);
+  * clean pseudo-labels are computed once per batch instead of once per
+    iteration (Q4: they are constant).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+# --------------------------------------------------------------------------- #
+# projections / prox (attacks/utils.py)
+# --------------------------------------------------------------------------- #
+
+
+def project_onto_l1_ball(x: Tensor, eps: float) -> Tensor:
+    """Row-wise Euclidean projection onto {||row||_1 <= eps} (utils.py:21-41).
+
+    Duchi et al. sort-based algorithm, restated explicitly:
+      mask_i   = ||x_i||_1 < eps                      (strict, utils.py:33)
+      mu       = sort(|x_i|, descending)              (utils.py:34)
+      c_j      = cumsum(mu)_j                         (utils.py:35)
+      rho      = max{ j : mu_j * j > c_j - eps }      (1-based, utils.py:37)
+      theta    = (c_rho - eps) / rho                  (utils.py:38)
+      out_i    = mask ? x_i : sign(x_i) * max(|x_i| - theta, 0)   (utils.py:39-40)
+    """
+    shape = x.shape
+    x2 = x.reshape(shape[0], -1)
+    n, k = x2.shape
+    absx = x2.abs()
+    inside = (absx.sum(dim=1) < eps).to(x2.dtype).unsqueeze(1)
+    mu, _ = torch.sort(absx, dim=1, descending=True)
+    csum = torch.cumsum(mu, dim=1)
+    j = torch.arange(1, k + 1, device=x2.device)
+    cond = (mu * j > (csum - eps))
+    rho = (cond * j).max(dim=1).values                       # in [0, k]; 0 only if no j satisfies
+    theta = (csum[torch.arange(n), rho - 1] - eps) / rho     # rho==0 -> index -1, /0 (reference behaviour)
+    proj = (absx - theta.unsqueeze(1)).clamp(min=0)
+    out = inside * x2 + (1 - inside) * proj * torch.sign(x2)
+    return out.reshape(shape)
+
+
+def constraint_dict(d: Tensor, constr_set: str = "l2ball") -> Tensor:
+    """Per-atom constraint on D (C,H,W,K) (utils.py:44-57). Returns a new tensor
+    (the reference mutates its argument in place and returns it)."""
+    d = d.clone()
+    k = d.shape[-1]
+    for a in range(k):
+        atom = d[..., a]
+        if constr_set == "l2sphere":
+            d[..., a] = atom / atom.norm(p="fro")
+        elif constr_set == "l2ball":
+            nrm = atom.norm(p="fro")
+            d[..., a] = atom / torch.maximum(nrm, torch.ones_like(nrm))
+        else:
+            d[..., a] = project_onto_l1_ball(atom, eps=1)
+    return d
+
+
+def clamp_image(img: Tensor, max_val: float = 1.0, min_val: float = 0.0) -> Tensor:
+    """utils.py:17-18."""
+    return img.clamp(min=min_val, max=max_val)
+
+
+def softshrink(x: Tensor, lam) -> Tensor:
+    """prox of lam*||.||_1 == torch.nn.Softshrink(lam) (utils.py:159-161)."""
+    lam = float(lam)
+    return torch.where(x > lam, x - lam, torch.where(x < -lam, x + lam, torch.zeros_like(x)))
+
+
+def get_slices(n: int, step: int) -> List[List[int]]:
+    """utils.py:153-156."""
+    return [list(range(i, min(i + step, n))) for i in range(0, n, step)]
+
+
+def get_target(model, img: Tensor, label: Tensor, targeted: bool) -> Tensor:
+    """utils.py:164-174: second most probable class when targeted, else label."""
+    if not targeted:
+        return label
+    with torch.no_grad():
+        return model(img).sort(dim=1).indices[:, -2]
+
+
+def projection_v(var: Tensor, eps: float, norm: str) -> Tensor:
+    """adil.py:625-633."""
+    if norm == "l2":
+        nrm = var.norm(p="fro", dim=1, keepdim=True)
+        return eps * var / torch.maximum(nrm, eps * torch.ones_like(nrm))
+    return project_onto_l1_ball(var, eps)
+
+
+def projection_d(var: Tensor, norm: str) -> Tensor:
+    """adil.py:635-642."""
+    if norm == "l2":
+        return constraint_dict(var, "l2ball")
+    return var.clamp(min=-1, max=1)
+
+
+# --------------------------------------------------------------------------- #
+# contractions (adil.py:25, 523-525, 542-543)
+# --------------------------------------------------------------------------- #
+
+
+def dict_matrix(d: Tensor) -> Tensor:
+    """(C,H,W,K) contiguous -> row-major P x K view (atom index innermost)."""
+    return d.reshape(-1, d.shape[-1])
+
+
+def synth(x: Tensor, d: Tensor, v_rows: Tensor) -> Tensor:
+    """x + tensordot(v_rows, d, ([1],[3]))  (adil.py:25-26)."""
+    b = x.shape[0]
+    dv = (v_rows @ dict_matrix(d).t()).reshape(x.shape)
+    return x + dv
+
+
+def grad_dv(g: Tensor, d: Tensor, v_rows: Tensor) -> Tuple[Tensor, Tensor]:
+    """Adjoint of synth for an upstream gradient g = dLoss/d(x+dv):
+    grad_d = g^T v_rows  (P x K, as (C,H,W,K));  grad_v_rows = g D  (B x K)."""
+    g2 = g.reshape(g.shape[0], -1)
+    gd = (g2.t() @ v_rows).reshape(d.shape)
+    gv = g2 @ dict_matrix(d)
+    return gd, gv
+
+
+def gram_pinv(d: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """DtD, its inverse, and D_dagger (K,C,H,W) (adil.py:523-525)."""
+    dm = dict_matrix(d)
+    dtd = dm.t() @ dm
+    dtd_inv = dtd.inverse()
+    d_drg = (dtd_inv @ dm.t()).reshape((d.shape[-1],) + tuple(d.shape[:-1]))
+    return dtd, dtd_inv, d_drg
+
+
+# --------------------------------------------------------------------------- #
+# optimiser (torch.optim.AdamW defaults used at adil.py:154,250-251,531,588)
+# --------------------------------------------------------------------------- #
+
+
+class AdamWState:
+    """Explicit single-tensor AdamW, torch semantics:
+        p *= 1 - lr*wd
+        m  = b1*m + (1-b1)*g ;  v = b2*v + (1-b2)*g*g
+        p -= (lr / (1-b1^t)) * m / ( sqrt(v)/sqrt(1-b2^t) + eps )
+    """
+
+    def __init__(self, p: Tensor, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        self.lr, self.b1, self.b2, self.eps, self.wd = lr, betas[0], betas[1], eps, weight_decay
+        self.m = torch.zeros_like(p)
+        self.v = torch.zeros_like(p)
+        self.t = 0
+
+    def step(self, p: Tensor, g: Tensor) -> None:
+        self.t += 1
+        p.mul_(1.0 - self.lr * self.wd)
+        self.m.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
+        self.v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
+        bc1 = 1.0 - self.b1 ** self.t
+        bc2 = 1.0 - self.b2 ** self.t
+        step_size = self.lr / bc1
+        denom = (self.v.sqrt() / math.sqrt(bc2)).add_(self.eps)
+        p.addcdiv_(self.m, denom, value=-step_size)
+
+
+# --------------------------------------------------------------------------- #
+# losses (adil.py:103-112, 136, 517)
+# --------------------------------------------------------------------------- #
+
+
+def f_loss(outputs: Tensor, labels: Tensor, kappa: float, targeted: bool = False) -> Tensor:
+    """CW-style margin (adil.py:103-112).  NB the label logit is ZEROED, not
+    masked to -inf (quirk Q5), and the reference always takes the untargeted
+    branch because it reads torchattacks' `_targeted` (False)."""
+    one_hot = torch.eye(outputs.shape[1], device=outputs.device)[labels]
+    i = ((1 - one_hot) * outputs).max(dim=1).values
+    j = outputs[torch.arange(outputs.shape[0]), labels]
+    if targeted:
+        return (i - j).clamp(min=-kappa)
+    return (j - i).clamp(min=-kappa)
+
+
+def attack_loss(outputs: Tensor, labels: Tensor, loss: str, coeff: float, kappa: float, ce_reduction: str) -> Tensor:
+    if loss == "ce":
+        return coeff * F.cross_entropy(outputs, labels, reduction=ce_reduction)
+    if loss == "logits":
+        return f_loss(outputs, labels, kappa).sum()
+    raise ValueError(loss)
+
+
+def _input_grad(model, xt: Tensor, labels: Tensor, loss: str, coeff: float, kappa: float,
+                ce_reduction: str) -> Tuple[Tensor, Tensor, Tensor]:
+    """One classifier fwd+bwd at xt. Returns (logits, loss value, dLoss/dxt)."""
+    xt = xt.detach().requires_grad_(True)
+    out = model(xt)
+    ls = attack_loss(out, labels, loss, coeff, kappa, ce_reduction)
+    (g,) = torch.autograd.grad(ls, xt)
+    return out.detach(), ls.detach(), g
+
+
+# --------------------------------------------------------------------------- #
+# learners (adil.py:114-332)
+# --------------------------------------------------------------------------- #
+
+
+def learn_step_a(model, x: Tensor, index: Tensor, d: Tensor, v: Tensor, opt_d: AdamWState, opt_v: AdamWState,
+                 eps: float, loss: str, coeff: float, kappa: float):
+    """One hot-loop iteration of learn_dictionary_a (adil.py:168-191):
+    pseudo-labels, synth, classifier fwd/bwd, AdamW on (d, ALL rows of v),
+    l1-ball projection of all rows of v, clamp of d to [-1,1].
+    d, v and the optimiser states are updated in place.
+    Returns (loss value, #fooled measured at the pre-update iterate)."""
+    with torch.no_grad():
+        label = model(x).argmax(dim=-1)                                   # adil.py:172
+    xt = synth(x, d, v[index])                                            # adil.py:176 -> :25-26
+    out, ls, g = _input_grad(model, xt, label, loss, coeff, kappa, "sum")  # adil.py:179-185
+    fooled = int((out.argmax(dim=-1) != label).sum())                     # adil.py:177
+    gd, gv_rows = grad_dv(g, d, v[index])
+    gv = torch.zeros_like(v)
+    gv[index] = gv_rows                                                   # dense grad, zero rows elsewhere
+    opt_d.step(d, gd)                                                     # adil.py:186 (one optimiser, 2 params)
+    opt_v.step(v, gv)
+    v.copy_(project_onto_l1_ball(v, eps))                                 # adil.py:187 -> :29-31
+    d.clamp_(min=-1, max=1)                                               # adil.py:188 -> :33-35
+    return float(ls), fooled
+
+
+def learn_dictionary_a(model, images: Tensor, d0: Tensor, v0: Tensor, epochs_batches: Sequence[Sequence[Sequence[int]]],
+                       eps: float, step_size: float = 0.01, loss: str = "ce", targeted: bool = False,
+                       kappa: float = 50.0, val_images: Optional[Tensor] = None,
+                       val_batches: Optional[Sequence[Sequence[Sequence[int]]]] = None, n_atoms: Optional[int] = None,
+                       norm: str = "linf"):
+    """learn_dictionary_a (adil.py:114-210) with injected D0, V0 and batch order.
+
+    epochs_batches[e] is the list of index lists the shuffled DataLoader served
+    in epoch e (adil.py:130,168).  Returns dict(d, v, loss_all,
+    fooling_rate_all, val_fool, opt_d, opt_v)."""
+    n_img = images.shape[0]
+    coeff = 1.0 if targeted else -1.0
+    d, v = d0.clone(), v0.clone()
+    opt_d = AdamWState(d, lr=step_size)
+    opt_v = AdamWState(v, lr=step_size)
+    loss_all, fooling_rate_all = [], []
+    val_fool = None
+    for it, batches in enumerate(epochs_batches):
+        loss_full, fooled = 0.0, 0
+        for idx in batches:
+            index = torch.as_tensor(idx, dtype=torch.long)
+            ls, fl = learn_step_a(model, images[index], index, d, v, opt_d, opt_v, eps, loss, coeff, kappa)
+            loss_full += ls
+            fooled += fl
+        loss_all.append(loss_full / n_img)                                 # adil.py:194
+        fooling_rate_all.append(fooled / n_img)                            # adil.py:195
+        if val_images is not None:
+            cnt = 0
+            for idx in val_batches[it]:
+                vi = val_images[torch.as_tensor(idx, dtype=torch.long)]
+                cnt += forward_supervised_adamw(model, vi, d, eps, loss=loss, targeted=targeted, kappa=kappa,
+                                                norm=norm, mode="train")
+            val_fool = cnt / val_images.shape[0]                           # adil.py:199-205
+        if it > 1 and abs(loss_all[it] - loss_all[it - 1]) < 1e-6:         # adil.py:207
+            break
+    return dict(d=d, v=v, loss_all=loss_all, fooling_rate_all=fooling_rate_all, val_fool=val_fool,
+                opt_d=opt_d, opt_v=opt_v)
+
+
+def learn_dictionary_b(model, images: Tensor, d0: Tensor, v0: Tensor, outer_batches, eps: float, steps_inner: int,
+                       step_size: float = 0.01, loss: str = "ce", targeted: bool = False, kappa: float = 50.0):
+    """learn_dictionary_b (adil.py:212-332), alternating scheme.
+
+    outer_batches[o] = (v_epochs, d_epochs): for outer iteration o, the batch
+    index lists of the `steps_inner` V-step epochs and of the `steps_inner`
+    D-step epochs.  AdamW(d) has lr = 2*step_size, AdamW(v) lr = step_size
+    (adil.py:250-251).  Quirk Q11: the D-step loss bookkeeping only adds the
+    LAST batch of the LAST D epoch (adil.py:313-314)."""
+    n_img = images.shape[0]
+    coeff = 1.0 if targeted else -1.0
+    d, v = d0.clone(), v0.clone()
+    opt_d = AdamWState(d, lr=2 * step_size)
+    opt_v = AdamWState(v, lr=step_size)
+    loss_all, fooling_rate_all = [], []
+    for it, (v_epochs, d_epochs) in enumerate(outer_batches):
+        for batches in v_epochs:                                           # adil.py:265-289
+            for idx in batches:
+                index = torch.as_tensor(idx, dtype=torch.long)
+                x = images[index]
+                with torch.no_grad():
+                    label = model(x).argmax(dim=-1)
+                xt = synth(x, d, v[index])
+                _, _, g = _input_grad(model, xt, label, loss, coeff, kappa, "sum")
+                _, gv_rows = grad_dv(g, d, v[index])
+                gv = torch.zeros_like(v)
+                gv[index] = gv_rows
+                opt_v.step(v, gv)
+                v.copy_(project_onto_l1_ball(v, eps))
+        for batches in d_epochs:                                           # adil.py:292-314
+            loss_full, fooled = 0.0, 0
+            for idx in batches:
+                index = torch.as_tensor(idx, dtype=torch.long)
+                x = images[index]
+                with torch.no_grad():
+                    label = model(x).argmax(dim=-1)
+                xt = synth(x, d, v[index])
+                out, ls, g = _input_grad(model, xt, label, loss, coeff, kappa, "sum")
+                fooled += int((out.argmax(dim=-1) != label).sum())
+                gd, _ = grad_dv(g, d, v[index])
+                opt_d.step(d, gd)
+                d.clamp_(min=-1, max=1)
+            loss_full += float(ls)                                         # last batch only (Q11)
+        loss_all.append(loss_full / n_img)
+        fooling_rate_all.append(fooled / n_img)
+        if it > 1 and abs(loss_all[it] - loss_all[it - 1]) < 1e-6:
+            break
+    return dict(d=d, v=v, loss_all=loss_all, fooling_rate_all=fooling_rate_all, opt_d=opt_d, opt_v=opt_v)
+
+
+# --------------------------------------------------------------------------- #
+# inference (adil.py:460-623)
+# --------------------------------------------------------------------------- #
+
+
+def forward_supervised_ddrague(model, images: Tensor, d: Tensor, eps: float, steps_inference: int = 30,
+                               loss: str = "ce", targeted: bool = False, kappa: float = 50.0,
+                               return_trace: bool = False):
+    """forward_supervised_DDrague (adil.py:508-567): optimise z (B,C,H,W) with
+    AdamW(lr 1e-2), v = z D_dagger^T, dv = v D^T, clamp z to +-eps each step,
+    stop on max|dz| < 1e-6; output clamp(images + D D_dagger z, 0, 1).
+    Quirk Q6: only z is bounded, the perturbation D D_dagger z is not."""
+    coeff = 1.0 if targeted else -1.0
+    dm = dict_matrix(d)
+    _, _, d_drg = gram_pinv(d)
+    drg_m = d_drg.reshape(d.shape[-1], -1)                                 # K x P
+    z = torch.zeros_like(images)
+    opt = AdamWState(z, lr=1e-2)
+    with torch.no_grad():
+        labels = model(images).argmax(dim=-1)                              # adil.py:539 (constant)
+    iters = 0
+    for _ in range(int(steps_inference)):
+        iters += 1
+        z2 = z.reshape(z.shape[0], -1)
+        vcode = z2 @ drg_m.t()                                             # adil.py:542
+        xt = images + (vcode @ dm.t()).reshape(images.shape)               # adil.py:543-544
+        _, _, g = _input_grad(model, xt, labels, loss, coeff, kappa, "mean")
+        g2 = g.reshape(g.shape[0], -1)
+        gz = ((g2 @ dm) @ drg_m).reshape(z.shape)                          # chain rule through dv, v
+        z_old = z.clone()
+        opt.step(z, gz)                                                    # adil.py:554
+        z.clamp_(min=-eps, max=eps)                                        # adil.py:555
+        if (z - z_old).abs().max() < 1e-6:                                 # adil.py:559
+            break
+    z2 = z.reshape(z.shape[0], -1)
+    vcode = z2 @ drg_m.t()
+    adv = (images + (vcode @ dm.t()).reshape(images.shape)).clamp(min=0, max=1)   # adil.py:563-567
+    if return_trace:
+        return adv, dict(z=z, v=vcode, iters=iters, labels=labels)
+    return adv
+
+
+def forward_supervised_adamw(model, images: Tensor, d: Tensor, eps: float, loss: str = "ce", targeted: bool = False,
+                             kappa: float = 50.0, norm: str = "linf", mode: str = "train", max_iter: int = 100,
+                             return_trace: bool = False):
+    """forward_supervised_AdamW (adil.py:569-623): fixed D, v = zeros (B,K),
+    AdamW([v], lr 1e-2), up to 100 iterations of {fwd/bwd, step, l1-ball
+    projection}, stop on max|dv| < 1e-6.  mode 'train' returns the fooled COUNT
+    (adil.py:619-620), otherwise clamp(images + D proj(v), 0, 1)."""
+    coeff = 1.0 if targeted else -1.0
+    b, k = images.shape[0], d.shape[-1]
+    v = torch.zeros(b, k, dtype=images.dtype)
+    opt = AdamWState(v, lr=1e-2)
+    with torch.no_grad():
+        labels = model(images).argmax(dim=-1)                              # adil.py:598 (constant)
+    iters = 0
+    for _ in range(max_iter):
+        iters += 1
+        xt = synth(images, d, v)
+        _, _, g = _input_grad(model, xt, labels, loss, coeff, kappa, "mean")
+        _, gv = grad_dv(g, d, v)
+        v_old = v.clone()
+        opt.step(v, gv)                                                    # adil.py:609
+        v.copy_(project_onto_l1_ball(v, eps))                              # adil.py:610 (always l1, Q2)
+        if (v - v_old).abs().max() < 1e-6:                                 # adil.py:614
+            break
+    xt = synth(images, d, projection_v(v, eps, norm))                      # adil.py:617
+    if mode == "train":
+        with torch.no_grad():
+            res = int((model(xt).argmax(dim=-1) != labels).sum())
+    else:
+        res = xt.clamp(min=0, max=1)
+    if return_trace:
+        return res, dict(v=v, iters=iters, labels=labels)
+    return res
+
+
+def forward_unsupervised(model, images: Tensor, d: Tensor, eps: float, v_trials: Sequence[Tensor]):
+    """forward_unsupervised (adil.py:460-506) with the sampled codes injected
+    (v_trials[t] is the (B,K) output of sample_sphere for trial t).
+    Returns (adv_best, dv_norm_inf of the LAST trial) — quirk Q12."""
+    n = images.shape[0]
+    fooling_flag = torch.zeros(n, dtype=torch.bool)
+    mse_best_do_fool = torch.full((n,), float("inf"))
+    mse_best_no_fool = torch.full((n,), float("inf"))
+    adv_best = images.clone()
+    dv_norm_inf: List[float] = []
+    with torch.no_grad():
+        pre = model(images).argmax(dim=1)
+        for v in v_trials:
+            dv = (v @ dict_matrix(d).t()).reshape(images.shape).clamp(min=-eps, max=eps)   # adil.py:481-482
+            dv_norm_inf = [float(dv[i].abs().max()) for i in range(n)]
+            adv = clamp_image(images + dv)                                                  # adil.py:484
+            fooling = model(adv).argmax(dim=1) != pre
+            mse = ((images - adv) ** 2).sum(dim=[1, 2, 3])
+            for i in range(n):                                                              # adil.py:494-504
+                if (not fooling_flag[i]) and fooling[i]:
+                    fooling_flag[i] = True
+                    mse_best_do_fool[i] = mse[i]
+                    adv_best[i] = adv[i]
+                elif (fooling_flag[i] and fooling[i]) or ((not fooling_flag[i]) and (not fooling[i])):
+                    if mse[i] < mse_best_no_fool[i]:
+                        mse_best_no_fool[i] = mse[i]
+                        adv_best[i] = adv[i]
+    return adv_best, dv_norm_inf
+
+
+def sample_sphere_from_uniform(u: Tensor, eps: float, norm: str) -> Tensor:
+    """sample_sphere (adil.py:644-655) with the uniform draw u ~ U[0,1)^(n,K) injected.
+    l2: var = 2u-1, eps*var/||var||;  linf: var = eps + eps*u (U(eps,2eps)), then l1-ball."""
+    if norm == "l2":
+        var = 2 * u - 1
+        return eps * var / var.norm(p="fro", dim=1, keepdim=True)
+    return project_onto_l1_ball(eps + (2 * eps - eps) * u, eps)
+
+
+# --------------------------------------------------------------------------- #
+# ISTA family (adil_regularized.py)
+# --------------------------------------------------------------------------- #
+
+
+def _smooth_loss(model, images, labels, d, v, batches, coeff, l2, targeted):
+    """sum_b coeff*CE_sum(model(x+Dv), target) + .5*l2*||Dv||^2  (adil_regularized.py:109-114)."""
+    total = 0
+    for idx in batches:
+        x, y = images[idx], labels[idx]
+        dv = (v[idx] @ dict_matrix(d).t()).reshape(x.shape)
+        tgt = get_target(model, x, y, targeted)
+        total = total + coeff * F.cross_entropy(model(x + dv), tgt, reduction="sum") + 0.5 * l2 * (dv ** 2).sum()
+    return total
+
+
+def learn_coding_vectors(model, images: Tensor, labels: Tensor, dictionary: Tensor, targeted: bool = True,
+                         niter: int = 100, lambda_l1: float = 1.0, lambda_l2: float = 1.0,
+                         batch_size: Optional[int] = None, step_size: float = 0.1):
+    """learn_coding_vectors (adil_regularized.py:508-628): ISTA on V with fixed D
+    and a backtracking line search (delta=.9, beta=.5, at most 11 trials)."""
+    n_img, k = images.shape[0], dictionary.shape[-1]
+    delta, gamma, beta = 0.9, 1.0, 0.5
+    batch_size = n_img if batch_size is None else batch_size
+    coeff = 1.0 if targeted else -1.0
+    batches = get_slices(n_img, batch_size)
+    d = dictionary
+    v = torch.zeros(n_img, k)
+    loss_all = [float("nan")]
+    step_size = float(step_size)
+    for _ in range(int(niter)):
+        v = v.detach().requires_grad_(True)
+        ls = _smooth_loss(model, images, labels, d, v, batches, coeff, lambda_l2, targeted)
+        loss_old = float((ls + lambda_l1 * v.abs().sum()).detach())
+        (grad_v,) = torch.autograd.grad(ls, v)
+        with torch.no_grad():
+            v_old = v.detach().clone()
+            v = softshrink(v_old - step_size * grad_v, step_size * lambda_l1)          # :570-573
+            d_v = v - v_old
+            h = float((d_v * grad_v).sum() + 0.5 * (gamma / step_size) * d_v.norm() ** 2
+                      + lambda_l1 * v.abs().sum() - lambda_l1 * v_old.abs().sum())    # :579-580
+            index_i = 0
+            while True:                                                                # :585-620
+                new_v = v_old + (delta ** index_i) * d_v
+                loss_full = float(_smooth_loss(model, images, labels, d, new_v, batches, coeff, lambda_l2, targeted)
+                                  + lambda_l1 * new_v.abs().sum())
+                if index_i == 0:
+                    loss_cur = loss_full
+                crit = loss_old + beta * (delta ** index_i) * h
+                if loss_full <= crit:
+                    if loss_cur > loss_full:
+                        v = new_v
+                        step_size = step_size * delta ** index_i
+                        loss_all.append(loss_full)
+                    else:
+                        loss_all.append(loss_cur)
+                    break
+                index_i += 1
+                if index_i > 10:
+                    v = new_v
+                    loss_all.append(loss_full)
+                    break
+        if loss_all[-2] - loss_all[-1] < 1e-6:                                         # :625
+            break
+    return v.detach(), loss_all
+
+
+def adil_full_batch(model, images: Tensor, labels: Tensor, d0: Tensor, targeted: bool = True, niter: int = 10,
+                    lambda_coding: float = 1.0, l2_fool: float = 1.0, batchsize: Optional[int] = None,
+                    step_size: float = 0.1, dict_set: str = "l2ball"):
+    """adil() (adil_regularized.py:31-197): full-batch forward-backward on (D,V)
+    with a secant Lipschitz estimate (:126-130) and a line search of at most 51
+    trials (delta=.5, beta=.5).  d0 is the already-constrained initial D."""
+    n_img, k = images.shape[0], d0.shape[-1]
+    delta, gamma, beta = 0.5, 1.0, 0.5
+    lipschitz = 0.9 / step_size
+    batchsize = n_img if batchsize is None else batchsize
+    coeff = 1.0 if targeted else -1.0
+    batches = get_slices(n_img, batchsize)
+    d, v = d0.clone(), torch.zeros(n_img, k)
+    d_old, v_old = torch.zeros_like(d), torch.zeros_like(v)
+    grad_v_old, grad_d_old = torch.zeros_like(v), torch.zeros_like(d)
+    loss_all = [float("nan")] * int(niter)
+    loss_non_smooth_old = 0.0
+    flag_stop = False
+    for it in range(int(niter)):
+        if flag_stop:
+            continue
+        v = v.detach().requires_grad_(True)
+        d = d.detach().requires_grad_(True)
+        loss_non_smooth = lambda_coding * v.abs().sum()
+        ls = _smooth_loss(model, images, labels, d, v, batches, coeff, l2_fool, targeted)
+        loss_full = ls + loss_non_smooth
+        grad_v, grad_d = torch.autograd.grad(ls, [v, d])
+        with torch.no_grad():
+            v, d = v.detach(), d.detach()
+            if it > 1:                                                                  # :126-130
+                lipschitz = torch.sqrt((grad_v - grad_v_old).norm() ** 2 + (grad_d - grad_d_old).norm() ** 2) \
+                    / torch.sqrt((v - v_old).norm() ** 2 + (d - d_old).norm() ** 2)
+            d_old.copy_(d); v_old.copy_(v); grad_v_old.copy_(grad_v); grad_d_old.copy_(grad_d)
+            loss_old = loss_full.detach()
+            step = 0.9 / lipschitz
+            v = softshrink(v - step * grad_v, step * lambda_coding)                    # :141-144
+            d = constraint_dict(d - step * grad_d, dict_set)                           # :146-147
+            d_v, d_d = v - v_old, d - d_old
+            h = (d_d * grad_d).sum() + (d_v * grad_v).sum() + 0.5 * (gamma / step) * (d_d.norm() ** 2 + d_v.norm() ** 2) \
+                + loss_non_smooth.detach() - loss_non_smooth_old                       # :154-156
+            index_i = 0
+            while True:                                                                # :161-192
+                new_v = v_old + (delta ** index_i) * d_v
+                new_d = d_old + (delta ** index_i) * d_d
+                loss_non_smooth = lambda_coding * new_v.abs().sum()
+                loss_full = _smooth_loss(model, images, labels, new_d, new_v, batches, coeff, l2_fool, targeted) \
+                    + loss_non_smooth
+                crit = loss_old + beta * (delta ** index_i) * h
+                if loss_full <= crit:
+                    v, d = new_v, new_d
+                    loss_non_smooth_old = loss_non_smooth.detach()
+                    break
+                index_i += 1
+                if index_i > 50:
+                    flag_stop = True
+                    break
+            loss_all[it] = float(loss_full)
+    return d.detach(), v.detach(), loss_all
+
+
+def sadil(model, images: Tensor, labels: Tensor, d0: Tensor, targeted: bool = True, nepochs: int = 3,
+          batchsize: int = 1, lambda_coding: float = 1.0, l2_fool: float = 1.0, stepsize: float = 1.0,
+          dict_set: str = "l2ball"):
+    """sadil() (adil_regularized.py:200-312): stochastic D-step then V-step per batch.
+
+    Quirk Q13 reproduced: `v` stays the same leaf for the whole run and its
+    .grad is never zeroed, so the V-step uses the gradient ACCUMULATED over all
+    previous backward passes (:299-304) — including the D-step backward passes
+    once v.requires_grad has been switched on by the first V-step (:291); D is
+    re-created each D-step so its gradient is fresh."""
+    n_img, k = images.shape[0], d0.shape[-1]
+    coeff = 1.0 if targeted else -1.0
+    batches = get_slices(n_img, batchsize)
+    d, v = d0.clone(), torch.zeros(n_img, k)
+    grad_v_acc = torch.zeros_like(v)
+    v_tracks_grad = False
+
+    def total_loss(vv, dd):
+        with torch.no_grad():
+            return float(_smooth_loss(model, images, labels, dd, vv, batches, coeff, l2_fool, targeted)) \
+                + float(lambda_coding * vv.abs().sum())
+
+    loss = [total_loss(v, d)]
+    for _ in range(int(nepochs)):
+        for idx in batches:
+            dd = d.detach().requires_grad_(True)
+            vv = v.detach().requires_grad_(v_tracks_grad)
+            ls = _smooth_loss(model, images, labels, dd, vv, [idx], coeff, l2_fool, targeted)
+            if v_tracks_grad:
+                grad_d, gv = torch.autograd.grad(ls, [dd, vv])
+                grad_v_acc += gv
+            else:
+                (grad_d,) = torch.autograd.grad(ls, dd)
+            with torch.no_grad():
+                d = constraint_dict(d - stepsize * grad_d, dict_set)                   # :283-284
+            v_tracks_grad = True                                                        # :291
+            vv = v.detach().requires_grad_(True)
+            ls = _smooth_loss(model, images, labels, d, vv, [idx], coeff, l2_fool, targeted)
+            (gv,) = torch.autograd.grad(ls, vv)
+            grad_v_acc += gv                                                            # accumulation (Q13)
+            with torch.no_grad():
+                v[idx] = softshrink(v[idx] - stepsize * grad_v_acc[idx], stepsize * lambda_coding)   # :304
+        loss.append(total_loss(v, d))
+        if abs(loss[-1] - loss[-2]) < 1e-6:
+            break
+    return d, v, loss
+
+
+# --------------------------------------------------------------------------- #
+# evaluation metrics (performance.py:154-266)
+# --------------------------------------------------------------------------- #
+
+
+def compute_fooling_rate(model, adversary: Tensor, clean: Tensor) -> float:
+    """performance.py:238-246 (reduction='sum')."""
+    with torch.no_grad():
+        return float((model(clean).argmax(dim=1) != model(adversary).argmax(dim=1)).float().sum())
+
+
+def compute_rmse(adversary: Tensor, clean: Tensor) -> float:
+    """performance.py:249-257 (reduction='sum')."""
+    upper = ((adversary - clean) ** 2).sum(dim=[1, 2, 3])
+    lower = (clean ** 2).sum(dim=[1, 2, 3])
+    return float((upper / lower).sum())
+
+
+def compute_mse(adversary: Tensor, clean: Tensor) -> float:
+    """performance.py:260-266 (reduction='sum')."""
+    return float(((adversary - clean) ** 2).sum(dim=[1, 2, 3]).sum())
+
+
+def performance(attack_fn: Callable[[Tensor, Tensor], Tensor], model, batches: Sequence[Tuple[Tensor, Tensor]]):
+    """performance() (performance.py:154-177): keep correctly classified samples,
+    attack them, accumulate fooling / rmse / mse sums, divide by #kept."""
+    num, fooling, rmse, mse = 0, 0.0, 0.0, 0.0
+    for x, y in batches:
+        with torch.no_grad():
+            keep = model(x).argmax(dim=-1) == y
+        x, y = x[keep], y[keep]
+        num += int(keep.sum())
+        adv = attack_fn(x, y).detach()
+        fooling += compute_fooling_rate(model, adv, x)
+        rmse += compute_rmse(adv, x)
+        mse += compute_mse(adv, x)
+    return dict(fooling_rate=fooling / num, rmse=rmse / num, mse=mse / num, num_samples=num)
