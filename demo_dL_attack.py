@@ -1,0 +1,106 @@
+"""Dictionary-learning + evaluation CLI — drop-in for the reference's demo_dL_attack.py on the MI355X engine.
+
+Reference flags are kept (--model/-m, --seed/-s, --num-train-per-class, --trained-classes, --distributed, --gpu,
+--steps-inference; demo_dL_attack.py:160-204) with the same defaults and the same hard-coded experiment
+(eps 8/255, linf, K=100, 500 steps, lr .01, batch 100, loss 'logits', method 'gd'; :88-118).
+Additions, all optional: model names of BASELINE.json (resnet18/resnet50/densenet121/vit_b_16), --weights (local
+torchvision state_dict), --synthetic (seeded stand-in dataset when the ILSVRC files are absent), and overrides
+--n-atoms/--steps/--batch-size/--dtype for plumbing runs."""
+import argparse
+import os
+import random
+
+import numpy as np
+import torch
+
+import performance as perf
+from attacks import ADIL
+from dl_attack_on_imagenet_amd import zoo
+from imagenet_loading import SyntheticImageNet, dataset_split_by_class, load_ImageNet
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--model', '-m', metavar='M', default='mobilenet')
+    p.add_argument('--seed', '-s', metavar='S', type=int, default=3, help='change seed to carry out the exp')
+    p.add_argument('--num-train-per-class', type=int, default=1, help='number per class for training')
+    p.add_argument('--trained-classes', metavar='TC', type=int, default=1000, help='number of class for training')
+    p.add_argument('--distributed', metavar='D', type=bool, default=False,
+                   help='If distributed data parallel used, default value is False')
+    p.add_argument('--gpu', type=int, default=0, help='gpu index, default is 0')
+    p.add_argument('--steps-inference', type=int, default=100, help='number of steps for inference, default is 100')
+    # additions
+    p.add_argument('--weights', default=None, help='local torchvision state_dict for the classifier')
+    p.add_argument('--synthetic', action='store_true', help='use a seeded synthetic dataset (no ILSVRC files needed)')
+    p.add_argument('--synthetic-classes', type=int, default=10)
+    p.add_argument('--image-size', type=int, default=224)
+    p.add_argument('--n-atoms', type=int, default=100)
+    p.add_argument('--steps', type=int, default=500)
+    p.add_argument('--batch-size', type=int, default=100)
+    p.add_argument('--loss', default='logits', choices=['logits', 'ce'])
+    p.add_argument('--method', default='gd', choices=['gd', 'alter'])
+    p.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'])
+    return p
+
+
+def main(args):
+    if not torch.cuda.is_available():
+        print('Check cuda setting for model training on ImageNet')       # demo_dL_attack.py:30-32
+        return
+    if not args.distributed:
+        torch.cuda.set_device(args.gpu)
+        device = torch.device('cuda', args.gpu)
+    else:
+        device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+        torch.cuda.set_device(device)
+
+    model_name = zoo.canonical_name(args.model)
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    model = zoo.build_classifier(model_name, seed=args.seed, weights=args.weights, device=device, dtype=dtype)
+
+    if args.synthetic:
+        dataset = SyntheticImageNet(num_classes=args.synthetic_classes, size=args.image_size, seed=args.seed)
+        n_classes = min(args.trained_classes, args.synthetic_classes)
+    else:
+        dataset, _ = load_ImageNet()
+        n_classes = args.trained_classes
+    train_dataset, val_dataset, test_dataset = dataset_split_by_class(
+        dataset, [args.num_train_per_class, 2, 5], number_of_classes=n_classes)         # demo_dL_attack.py:69-78
+    val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=10, shuffle=False)
+    test_loader = torch.utils.data.DataLoader(test_dataset, batch_size=20, shuffle=False)
+
+    eps, norm = 8 / 255, 'linf'
+    attacks_hyper = {
+        'adil': perf.get_atks(model, ADIL, 'n_atoms', [args.n_atoms], 'kappa', [50], alpha=0 / 255,
+                              data_train=train_dataset, norm=norm, attack='supervised', eps=eps, steps=args.steps,
+                              targeted=False, step_size=0.01, batch_size=args.batch_size, model_name=model_name,
+                              is_distributed=args.distributed, steps_in=1, loss=args.loss, method=args.method,
+                              data_val=val_dataset, warm_start=False, steps_inference=args.steps_inference,
+                              stream_dtype=dtype if dtype != torch.float32 else None),
+    }
+    out_dir = 'dict_model_ImageNet_version_constrained'
+    os.makedirs(out_dir, exist_ok=True)                                                   # quirk Q14: upstream assumes it exists
+    print('Evaluation process')
+    val_perf = perf.get_performance(attacks_hyper, model, _cast_loader(val_loader, dtype), device=device)
+    torch.save(val_perf, os.path.join(out_dir, f'model_sampling_adil_inference_rlts_sampling_'
+                                               f'{args.num_train_per_class * n_classes}_{args.steps_inference}_'
+                                               f'{args.seed}_ce.bin'))
+    print('Test process')
+    test_perf = perf.get_performance(attacks_hyper, model, _cast_loader(test_loader, dtype), device=device)
+    torch.save(test_perf, os.path.join(out_dir, 'model_adil_resultat_test_ce.bin'))
+    return val_perf, test_perf
+
+
+def _cast_loader(loader, dtype):
+    if dtype == torch.float32:
+        return loader
+    return [(x.to(dtype), y) for x, y in loader]
+
+
+if __name__ == '__main__':
+    args = build_parser().parse_args()
+    print(args.seed)
+    torch.random.manual_seed(args.seed)                                                   # demo_dL_attack.py:209-211
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    main(args)

@@ -1,0 +1,501 @@
+// ADiL parameter-update kernels for gfx950: fused AdamW + projections, prox, atom
+// constraints, Gram / pseudo-inverse helpers and evaluation sums.  All HBM-bound
+// elementwise / row-wise work: 16-byte vector accesses, one pass per stream.
+#include "adil_common.h"
+
+// --------------------------------------------------------------------------- //
+// AdamW (torch.optim.AdamW single-tensor semantics) on one element
+// --------------------------------------------------------------------------- //
+struct AdamWHyper {
+    float decay;      // 1 - lr*wd
+    float b1, b2;     // betas
+    float eps;
+    float step_size;  // lr / (1 - b1^t)
+    float bc2_sqrt;   // sqrt(1 - b2^t)
+};
+
+__device__ __forceinline__ float adamw_elem(float p, float g, float& m, float& s, const AdamWHyper& h) {
+    p *= h.decay;
+    m = m + (1.0f - h.b1) * (g - m);                 // exp_avg.lerp_(grad, 1-b1)
+    s = s * h.b2 + (1.0f - h.b2) * g * g;            // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+    float denom = sqrtf(s) / h.bc2_sqrt + h.eps;
+    return p - h.step_size * (m / denom);
+}
+
+// ---- K4 / K8: flat AdamW + clamp[lo,hi] (+ max|delta|) --------------------- //
+template <typename GT>
+__global__ __launch_bounds__(256) void adamw_clamp_kernel(float* __restrict__ p, const GT* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ s, size_t n,
+                                                          AdamWHyper h, float lo, float hi, float* max_abs_delta) {
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float local_max = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pv = reinterpret_cast<const float4*>(p)[i];
+        float4 mv = reinterpret_cast<const float4*>(m)[i];
+        float4 sv = reinterpret_cast<const float4*>(s)[i];
+        float gv[4];
+        if constexpr (sizeof(GT) == 4) {
+            float4 t = reinterpret_cast<const float4*>(g)[i];
+            gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
+        } else {
+            ushort4 t = reinterpret_cast<const ushort4*>(g)[i];
+            gv[0] = bf16_to_f32(t.x); gv[1] = bf16_to_f32(t.y); gv[2] = bf16_to_f32(t.z); gv[3] = bf16_to_f32(t.w);
+        }
+        float po[4] = {pv.x, pv.y, pv.z, pv.w};
+        float mo[4] = {mv.x, mv.y, mv.z, mv.w};
+        float so[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float q = adamw_elem(po[j], gv[j], mo[j], so[j], h);
+            q = fminf(fmaxf(q, lo), hi);
+            local_max = fmaxf(local_max, fabsf(q - po[j]));
+            po[j] = q;
+        }
+        reinterpret_cast<float4*>(p)[i] = make_float4(po[0], po[1], po[2], po[3]);
+        reinterpret_cast<float4*>(m)[i] = make_float4(mo[0], mo[1], mo[2], mo[3]);
+        reinterpret_cast<float4*>(s)[i] = make_float4(so[0], so[1], so[2], so[3]);
+    }
+    // tail (n % 4 elements), handled by the first threads of block 0
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        size_t i = n4 * 4 + threadIdx.x;
+        float mm = m[i], ss = s[i], p0 = p[i];
+        float q = adamw_elem(p0, Elem<GT>::load(g, i), mm, ss, h);
+        q = fminf(fmaxf(q, lo), hi);
+        local_max = fmaxf(local_max, fabsf(q - p0));
+        p[i] = q; m[i] = mm; s[i] = ss;
+    }
+    if (max_abs_delta != nullptr) {
+        local_max = wave_max(local_max);
+        if ((threadIdx.x & 63) == 0 && local_max > 0.0f) atomic_max_nonneg(max_abs_delta, local_max);
+    }
+}
+
+// --------------------------------------------------------------------------- //
+// Row-wise l1-ball projection inside one wavefront (Duchi et al.), K <= 64*EPL.
+// Sort-free: every element finds its descending rank and the prefix sum at that
+// rank by sweeping the row once through v_readlane broadcasts.
+// --------------------------------------------------------------------------- //
+template <int EPL>
+__device__ __forceinline__ void l1ball_row(float (&x)[EPL], int lane, float radius) {
+    float a[EPL];
+    float l1 = 0.0f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { a[e] = fabsf(x[e]); l1 += a[e]; }
+    l1 = wave_sum(l1);
+    if (l1 < radius) return;                      // strict '<' (utils.py:33): rows inside the ball are untouched
+    int rank[EPL];
+    float pre[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { rank[e] = 1; pre[e] = a[e]; }
+#pragma unroll
+    for (int je = 0; je < EPL; ++je) {
+#pragma unroll
+        for (int jl = 0; jl < ADIL_WAVE; ++jl) {
+            const float aj = __shfl(a[je], jl, 64);
+            const int jidx = je * ADIL_WAVE + jl;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int iidx = e * ADIL_WAVE + lane;
+                const bool before = (aj > a[e]) || (aj == a[e] && jidx < iidx);
+                rank[e] += before ? 1 : 0;
+                pre[e] += before ? aj : 0.0f;
+            }
+        }
+    }
+    // rho = max{ rank : mu_rank * rank > cumsum_rank - radius }   (utils.py:37)
+    int rho = 0;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+        if (a[e] * (float)rank[e] > pre[e] - radius) rho = max(rho, rank[e]);
+    rho = wave_max_i(rho);
+    float c = 0.0f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) c += (rank[e] == rho) ? pre[e] : 0.0f;
+    c = wave_sum(c);                               // ranks are unique: exactly one contributor
+    const float theta = (c - radius) / (float)rho; // utils.py:38
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const float pr = fmaxf(a[e] - theta, 0.0f);
+        x[e] = (x[e] > 0.0f) ? pr : ((x[e] < 0.0f) ? -pr : 0.0f * pr);
+    }
+}
+
+// ---- K5: AdamW on all N rows of V + l1-ball projection --------------------- //
+template <int EPL>
+__global__ __launch_bounds__(256) void adamw_l1ball_kernel(float* __restrict__ v, const float* __restrict__ grad_vb,
+                                                           const int32_t* __restrict__ pos, float* __restrict__ m,
+                                                           float* __restrict__ s, int N, int K, AdamWHyper h,
+                                                           float radius, float* max_abs_delta, int do_adam) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= N) return;                          // whole wave exits together
+    int slot = row;
+    if (pos != nullptr) slot = pos[row];
+    float x[EPL], x_old[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int k = e * ADIL_WAVE + lane;
+        float val = 0.0f;
+        if (k < K) {
+            const size_t i = (size_t)row * K + k;
+            val = v[i];
+            x_old[e] = val;
+            if (do_adam) {
+                float mm = m[i], ss = s[i];
+                const float g = (slot >= 0) ? grad_vb[(size_t)slot * K + k] : 0.0f;
+                val = adamw_elem(val, g, mm, ss, h);
+                m[i] = mm; s[i] = ss;
+            }
+        } else {
+            x_old[e] = 0.0f;
+        }
+        x[e] = val;
+    }
+    if (radius >= 0.0f) l1ball_row<EPL>(x, lane, radius);
+    float dmax = 0.0f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int k = e * ADIL_WAVE + lane;
+        if (k < K) {
+            v[(size_t)row * K + k] = x[e];
+            dmax = fmaxf(dmax, fabsf(x[e] - x_old[e]));
+        }
+    }
+    if (max_abs_delta != nullptr) {
+        dmax = wave_max(dmax);
+        if (lane == 0 && dmax > 0.0f) atomic_max_nonneg(max_abs_delta, dmax);
+    }
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256) void l2ball_kernel(float* __restrict__ x, int N, int K, float radius) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= N) return;
+    float val[EPL];
+    float ss = 0.0f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int k = e * ADIL_WAVE + lane;
+        val[e] = (k < K) ? x[(size_t)row * K + k] : 0.0f;
+        ss += val[e] * val[e];
+    }
+    const float nrm = sqrtf(wave_sum(ss));
+    const float den = fmaxf(nrm, radius);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int k = e * ADIL_WAVE + lane;
+        if (k < K) x[(size_t)row * K + k] = radius * val[e] / den;
+    }
+}
+
+// ---- K10: ISTA step  v = softshrink(v - step*g, lam) ------------------------ //
+__global__ __launch_bounds__(256) void ista_kernel(float* __restrict__ v, const float* __restrict__ g, size_t n,
+                                                   float step, float lam) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float t = v[i];
+        if (g != nullptr) t = t - step * g[i];
+        v[i] = (t > lam) ? (t - lam) : ((t < -lam) ? (t + lam) : 0.0f);
+    }
+}
+
+// ---- gather + pad the batch's code rows ------------------------------------ //
+__global__ __launch_bounds__(256) void pack_codes_kernel(const float* __restrict__ v, const int64_t* __restrict__ index,
+                                                         int B, int K, int Kp, int Bp, float* __restrict__ vp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Bp * Kp) return;
+    const int b = i / Kp, k = i - b * Kp;
+    float val = 0.0f;
+    if (b < B && k < K) {
+        const int64_t row = (index != nullptr) ? index[b] : (int64_t)b;
+        val = v[row * K + k];
+    }
+    vp[i] = val;
+}
+
+// ---- K11: per-atom norms / scaling ------------------------------------------ //
+// partial[block][k] = sum over the block's rows of d[p][k]^2 ; then a tiny reduce.
+__global__ __launch_bounds__(256) void atom_sumsq_partial_kernel(const float* __restrict__ d, int P, int K, int KT,
+                                                                 int rows_per_block, float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int k = threadIdx.x % KT, r = threadIdx.x / KT, R = 256 / KT;
+    const int p_begin = blockIdx.x * rows_per_block;
+    const int p_end = min(P, p_begin + rows_per_block);
+    float acc = 0.0f;
+    if (k < K)
+        for (int p = p_begin + r; p < p_end; p += R) { const float t = d[(size_t)p * K + k]; acc += t * t; }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (r == 0) {
+        for (int rr = 1; rr < R; ++rr) acc += red[rr * KT + k];
+        if (k < K) partial[(size_t)blockIdx.x * K + k] = acc;
+    }
+}
+__global__ void atom_norm_finish_kernel(const float* __restrict__ partial, int nblocks, int K, float* __restrict__ norms) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float acc = 0.0f;
+    for (int b = 0; b < nblocks; ++b) acc += partial[(size_t)b * K + k];
+    norms[k] = sqrtf(acc);
+}
+__global__ __launch_bounds__(256) void atom_scale_kernel(float* __restrict__ d, size_t n, int K,
+                                                         const float* __restrict__ norms, int sphere) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float nk = norms[i % K];
+        d[i] = d[i] / (sphere ? nk : fmaxf(nk, 1.0f));
+    }
+}
+
+// ---- K7: Gram matrix partials and D * M^T ----------------------------------- //
+// Each block owns a contiguous row range; thread t owns outputs o = t, t+256, ...
+template <int MAXO>
+__global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ d, int P, int K,
+                                                           int rows_per_block, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float srow[];   // [32][K]
+    const int KK = K * K;
+    float acc[MAXO];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) acc[o] = 0.0f;
+    const int p_begin = blockIdx.x * rows_per_block;
+    const int p_end = min(P, p_begin + rows_per_block);
+    for (int p0 = p_begin; p0 < p_end; p0 += 32) {
+        const int nr = min(32, p_end - p0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * K; i += 256) srow[i] = d[(size_t)p0 * K + i];
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) {
+            const int oi = threadIdx.x + o * 256;
+            if (oi < KK) {
+                const int i = oi / K, j = oi - i * K;
+                float a = acc[o];
+                for (int r = 0; r < nr; ++r) a += srow[r * K + i] * srow[r * K + j];
+                acc[o] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) {
+        const int oi = threadIdx.x + o * 256;
+        if (oi < KK) partial[(size_t)blockIdx.x * KK + oi] = acc[o];
+    }
+}
+__global__ void sum_partials_kernel(const float* __restrict__ partial, int nblocks, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.0f;
+    for (int b = 0; b < nblocks; ++b) acc += partial[(size_t)b * n + i];
+    out[i] = acc;
+}
+
+// out[p][k] = sum_j d[p][j] * mat[k][j]
+__global__ __launch_bounds__(256) void dict_rightmul_kernel(const float* __restrict__ d, const float* __restrict__ mat,
+                                                            int P, int K, int KT, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // mat [K][K+1] then rows [R][K]
+    float* smat = sm;
+    float* srow = sm + K * (K + 1);
+    const int R = 256 / KT;
+    for (int i = threadIdx.x; i < K * K; i += 256) smat[(i / K) * (K + 1) + (i % K)] = mat[i];
+    const int k = threadIdx.x % KT, r = threadIdx.x / KT;
+    for (int p0 = blockIdx.x * R; p0 < P; p0 += gridDim.x * R) {
+        __syncthreads();
+        const int nr = min(R, P - p0);
+        for (int i = threadIdx.x; i < nr * K; i += 256) srow[i] = d[(size_t)p0 * K + i];
+        __syncthreads();
+        if (r < nr && k < K) {
+            float acc = 0.0f;
+            for (int j = 0; j < K; ++j) acc += srow[r * K + j] * smat[k * (K + 1) + j];
+            out[(size_t)(p0 + r) * K + k] = acc;
+        }
+    }
+}
+
+// ---- K12: per-image evaluation sums ----------------------------------------- //
+template <typename T>
+__global__ __launch_bounds__(256) void image_metrics_kernel(const T* __restrict__ adv, const T* __restrict__ x, int P,
+                                                            float* __restrict__ sq_err, float* __restrict__ sq_norm) {
+    __shared__ float red[2][4];
+    const size_t base = (size_t)blockIdx.x * P;
+    float e = 0.0f, q = 0.0f;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const float xv = Elem<T>::load(x, base + p);
+        const float dv = Elem<T>::load(adv, base + p) - xv;
+        e += dv * dv;
+        q += xv * xv;
+    }
+    e = wave_sum(e); q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = e; red[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sq_err[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        sq_norm[blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+// =========================================================================== //
+// C ABI
+// =========================================================================== //
+static inline int pow2_at_least(int k) { int t = 16; while (t < k) t <<= 1; return t; }
+static inline int stream_grid(size_t work_items, int per_block) {
+    size_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;                          // 256 CUs x 8 blocks, grid-stride the rest
+    return (int)b;
+}
+
+extern "C" int adil_abi_version(void) { return 1; }
+extern "C" int adil_max_atoms(void) { return ADIL_MAX_ATOMS; }
+
+extern "C" int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, void* stream) {
+    if (!v || !vp || B <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
+    const int Kp = round_up(K, 16), Bp = round_up(B, 32);
+    const int total = Bp * Kp;
+    hipLaunchKernelGGL(pack_codes_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, index, B, K,
+                       Kp, Bp, vp);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, float* s, size_t n, float decay,
+                                float b1, float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi,
+                                float* max_abs_delta, void* stream) {
+    if (!p || !g || !m || !s || n == 0) return ADIL_EINVAL;
+    if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)s | (uintptr_t)g) & 15) return ADIL_EINVAL;  // 16-B vector access
+    AdamWHyper h{decay, b1, b2, eps, step_size, bc2_sqrt};
+    const int grid = stream_grid(n / 4 + 1, 256);
+    if (g_dtype == ADIL_F32)
+        hipLaunchKernelGGL(adamw_clamp_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
+                           (const float*)g, m, s, n, h, lo, hi, max_abs_delta);
+    else if (g_dtype == ADIL_BF16)
+        hipLaunchKernelGGL(adamw_clamp_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
+                           (const bf16_t*)g, m, s, n, h, lo, hi, max_abs_delta);
+    else
+        return ADIL_EINVAL;
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+static int launch_adamw_l1ball(float* v, const float* grad_vb, const int32_t* pos, float* m, float* s, int N, int K,
+                               AdamWHyper h, float radius, float* max_abs_delta, int do_adam, hipStream_t st) {
+    const dim3 grid((N + 3) / 4), block(256);
+    if (K <= 64)
+        hipLaunchKernelGGL(adamw_l1ball_kernel<1>, grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
+                           max_abs_delta, do_adam);
+    else
+        hipLaunchKernelGGL(adamw_l1ball_kernel<2>, grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
+                           max_abs_delta, do_adam);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_adamw_l1ball(float* v, const float* grad_vb, const int32_t* pos, float* m, float* s, int N, int K,
+                                 float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt,
+                                 float radius, float* max_abs_delta, void* stream) {
+    if (!v || !grad_vb || !m || !s || N <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
+    AdamWHyper h{decay, b1, b2, eps, step_size, bc2_sqrt};
+    return launch_adamw_l1ball(v, grad_vb, pos, m, s, N, K, h, radius, max_abs_delta, 1, (hipStream_t)stream);
+}
+
+extern "C" int adil_l1ball_project(float* x, int N, int K, float radius, void* stream) {
+    if (!x || N <= 0 || K <= 0 || K > ADIL_MAX_ATOMS || radius < 0.0f) return ADIL_EINVAL;
+    AdamWHyper h{};
+    return launch_adamw_l1ball(x, nullptr, nullptr, nullptr, nullptr, N, K, h, radius, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int adil_l2ball_project(float* x, int N, int K, float radius, void* stream) {
+    if (!x || N <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
+    const dim3 grid((N + 3) / 4), block(256);
+    if (K <= 64) hipLaunchKernelGGL(l2ball_kernel<1>, grid, block, 0, (hipStream_t)stream, x, N, K, radius);
+    else hipLaunchKernelGGL(l2ball_kernel<2>, grid, block, 0, (hipStream_t)stream, x, N, K, radius);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_ista_step(float* v, const float* g, size_t n, float step, float lam, void* stream) {
+    if (!v || n == 0) return ADIL_EINVAL;
+    hipLaunchKernelGGL(ista_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, v, g, n, step, lam);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+static const int kAtomBlocks = 512;
+extern "C" size_t adil_atom_workspace_bytes(int P, int K) { (void)P; return (size_t)kAtomBlocks * K * sizeof(float); }
+
+extern "C" int adil_atom_norms(const float* d, int P, int K, float* norms, void* ws, size_t ws_bytes, void* stream) {
+    if (!d || !norms || !ws || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
+    if (ws_bytes < adil_atom_workspace_bytes(P, K)) return ADIL_EWORKSPACE;
+    const int rows_per_block = (P + kAtomBlocks - 1) / kAtomBlocks;
+    const int nblocks = (P + rows_per_block - 1) / rows_per_block;
+    const int KT = pow2_at_least(K);
+    hipLaunchKernelGGL(atom_sumsq_partial_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, d, P, K, KT,
+                       rows_per_block, (float*)ws);
+    ADIL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(atom_norm_finish_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, (const float*)ws, nblocks, K,
+                       norms);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_atom_scale(float* d, int P, int K, const float* norms, int sphere, void* stream) {
+    if (!d || !norms || P <= 0 || K <= 0) return ADIL_EINVAL;
+    const size_t n = (size_t)P * K;
+    hipLaunchKernelGGL(atom_scale_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, d, n, K, norms,
+                       sphere);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+static const int kGramBlocks = 256;
+extern "C" size_t adil_gram_workspace_bytes(int P, int K) { (void)P; return (size_t)kGramBlocks * K * K * sizeof(float); }
+
+extern "C" int adil_gram(const float* d, int P, int K, float* gram, void* ws, size_t ws_bytes, void* stream) {
+    if (!d || !gram || !ws || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
+    if (ws_bytes < adil_gram_workspace_bytes(P, K)) return ADIL_EWORKSPACE;
+    const int rows_per_block = (P + kGramBlocks - 1) / kGramBlocks;
+    const int nblocks = (P + rows_per_block - 1) / rows_per_block;
+    const size_t lds = (size_t)32 * K * sizeof(float);
+    const int KK = K * K;
+    if (KK <= 256 * 4)
+        hipLaunchKernelGGL(gram_partial_kernel<4>, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, d, P, K,
+                           rows_per_block, (float*)ws);
+    else if (KK <= 256 * 16)
+        hipLaunchKernelGGL(gram_partial_kernel<16>, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, d, P, K,
+                           rows_per_block, (float*)ws);
+    else
+        hipLaunchKernelGGL(gram_partial_kernel<64>, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, d, P, K,
+                           rows_per_block, (float*)ws);
+    ADIL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((KK + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
+                       nblocks, KK, gram);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_dict_rightmul(const float* d, const float* mat, int P, int K, float* out, void* stream) {
+    if (!d || !mat || !out || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
+    const int KT = pow2_at_least(K), R = 256 / KT;
+    const size_t lds = ((size_t)K * (K + 1) + (size_t)R * K) * sizeof(float);
+    int grid = (P + R - 1) / R;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(dict_rightmul_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, d, mat, P, K, KT, out);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_image_metrics(const void* adv, const void* x, int B, int P, int dtype, float* sq_err,
+                                  float* sq_norm, void* stream) {
+    if (!adv || !x || !sq_err || !sq_norm || B <= 0 || P <= 0) return ADIL_EINVAL;
+    if (dtype == ADIL_F32)
+        hipLaunchKernelGGL(image_metrics_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)adv,
+                           (const float*)x, P, sq_err, sq_norm);
+    else if (dtype == ADIL_BF16)
+        hipLaunchKernelGGL(image_metrics_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)adv,
+                           (const bf16_t*)x, P, sq_err, sq_norm);
+    else
+        return ADIL_EINVAL;
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}

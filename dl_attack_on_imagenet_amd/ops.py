@@ -1,0 +1,333 @@
+"""Tensor-level wrappers over the C ABI (include/adil_hip.h).
+
+PyTorch is used for device memory and streams only: every function takes CUDA
+(ROCm) tensors, passes raw device pointers + the current HIP stream through
+ctypes, and raises if handed anything the kernels cannot run on.  There is no
+CPU path.
+"""
+from __future__ import annotations
+
+import math
+from ctypes import c_void_p
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+Tensor = torch.Tensor
+_DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
+_workspaces = {}
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def stream_dtype_code(dtype: torch.dtype) -> int:
+    try:
+        return _DTYPE_CODE[dtype]
+    except KeyError:
+        raise TypeError(f"ADiL image streams must be float32 or bfloat16, got {dtype}") from None
+
+
+def _dev(t: Tensor, name: str, dtype: Optional[torch.dtype] = None) -> Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/ROCm tensor: the ADiL hot path runs on HIP kernels only "
+                           "(no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _ptr(t: Optional[Tensor]) -> c_void_p:
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _workspace(device: torch.device, nbytes: int) -> Tensor:
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def dict_shape(d: Tensor) -> Tuple[int, int]:
+    """(P, K) of a dictionary stored as the reference's (C,H,W,K) tensor (adil.py:20)."""
+    k = d.shape[-1]
+    return d.numel() // k, k
+
+
+# --------------------------------------------------------------------------- #
+@dataclass
+class AdamWScalars:
+    decay: float
+    b1: float
+    b2: float
+    eps: float
+    step_size: float
+    bc2_sqrt: float
+
+
+class AdamWSchedule:
+    """Host-side step counter of one torch.optim.AdamW param (defaults of adil.py:154: betas (0.9,0.999),
+    eps 1e-8, weight_decay 1e-2).  The scalars are formed in double exactly as torch forms them."""
+
+    def __init__(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        self.lr, self.b1, self.b2, self.eps, self.wd = float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay)
+        self.t = 0
+
+    def next(self) -> AdamWScalars:
+        self.t += 1
+        bc1 = 1.0 - self.b1 ** self.t
+        bc2 = 1.0 - self.b2 ** self.t
+        return AdamWScalars(1.0 - self.lr * self.wd, self.b1, self.b2, self.eps, self.lr / bc1, math.sqrt(bc2))
+
+
+# --------------------------------------------------------------------------- #
+def pack_codes(v: Tensor, index: Optional[Tensor], batch: Optional[int] = None) -> Tensor:
+    """vp [roundup(B,32)][roundup(K,16)] = zero-padded v[index] (adil.py:25 `self.v[index, :]`)."""
+    lib = _lib.load()
+    _dev(v, "v", torch.float32)
+    k = v.shape[1]
+    if index is not None:
+        index = _dev(index.to(device=v.device, dtype=torch.int64), "index")
+        b = index.numel()
+    else:
+        b = v.shape[0] if batch is None else batch
+    vp = torch.empty(_round_up(b, 32), _round_up(k, 16), dtype=torch.float32, device=v.device)
+    _lib.check(lib.adil_pack_codes(_ptr(v), _ptr(index), b, k, _ptr(vp), _stream()), "adil_pack_codes")
+    return vp
+
+
+def synth(x: Optional[Tensor], d: Tensor, vp: Tensor, batch: int, *, out: Optional[Tensor] = None,
+          out_shape=None, out_dtype=None, delta_clamp: float = -1.0, pixel_clamp: bool = False) -> Tensor:
+    """out = x + vp D^T with optional +-delta_clamp on the perturbation and [0,1] pixel clamp."""
+    lib = _lib.load()
+    _dev(d, "d", torch.float32)
+    _dev(vp, "vp", torch.float32)
+    p, k = dict_shape(d)
+    if x is not None:
+        _dev(x, "x")
+        if x.numel() != batch * p:
+            raise ValueError(f"x has {x.numel()} elements, expected B*P = {batch}*{p}")
+        out_shape, out_dtype = x.shape, x.dtype
+    if out is None:
+        out = torch.empty(out_shape, dtype=out_dtype, device=d.device)
+    _dev(out, "out", out_dtype)
+    if out.numel() != batch * p or vp.shape != (_round_up(batch, 32), _round_up(k, 16)):
+        raise ValueError("synth: operand shapes do not match (B, P, K)")
+    _lib.check(lib.adil_synth(_ptr(x), _ptr(d), _ptr(vp), _ptr(out), batch, p, k, stream_dtype_code(out.dtype),
+                              float(delta_clamp), int(bool(pixel_clamp)), _stream()), "adil_synth")
+    return out
+
+
+def grad(g: Tensor, d: Tensor, vp: Optional[Tensor], batch: int, *, want_d: bool = True, want_v: bool = True,
+         grad_d: Optional[Tensor] = None, accumulate_d: bool = False) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """(grad_d (C,H,W,K), grad_vb (B,K)) of the synthesis for upstream gradient g (B x P)."""
+    lib = _lib.load()
+    _dev(g, "g")
+    _dev(d, "d", torch.float32)
+    p, k = dict_shape(d)
+    if g.numel() != batch * p:
+        raise ValueError(f"g has {g.numel()} elements, expected B*P = {batch}*{p}")
+    gvb = None
+    ws, ws_bytes = None, 0
+    if want_d:
+        _dev(vp, "vp", torch.float32)
+        if vp.shape != (_round_up(batch, 32), _round_up(k, 16)):
+            raise ValueError("grad: vp shape does not match (B, K)")
+        if grad_d is None:
+            grad_d = torch.empty_like(d)
+            accumulate_d = False
+        _dev(grad_d, "grad_d", torch.float32)
+        if grad_d.shape != d.shape:
+            raise ValueError("grad_d must have the dictionary's shape")
+    else:
+        grad_d = None
+    if want_v:
+        gvb = torch.empty(batch, k, dtype=torch.float32, device=d.device)
+        ws_bytes = lib.adil_grad_workspace_bytes(batch, p, k)
+        ws = _workspace(d.device, ws_bytes)
+    _lib.check(lib.adil_grad(_ptr(g), _ptr(d), _ptr(vp), _ptr(grad_d), _ptr(gvb), batch, p, k,
+                             stream_dtype_code(g.dtype), int(bool(accumulate_d)), _ptr(ws), ws_bytes, _stream()),
+               "adil_grad")
+    return grad_d, gvb
+
+
+def adamw_clamp_(p: Tensor, g: Tensor, m: Tensor, s: Tensor, h: AdamWScalars, lo: float, hi: float,
+                 max_abs_delta: Optional[Tensor] = None) -> None:
+    """In-place fused AdamW + clamp[lo,hi] on a flat fp32 parameter (adil.py:186,188 / :554-555)."""
+    lib = _lib.load()
+    for name, t in (("p", p), ("m", m), ("s", s)):
+        _dev(t, name, torch.float32)
+    _dev(g, "g")
+    if not (p.numel() == g.numel() == m.numel() == s.numel()):
+        raise ValueError("adamw_clamp_: size mismatch")
+    if max_abs_delta is not None:
+        _dev(max_abs_delta, "max_abs_delta", torch.float32)
+    _lib.check(lib.adil_adamw_clamp(_ptr(p), _ptr(g), stream_dtype_code(g.dtype), _ptr(m), _ptr(s), p.numel(),
+                                    h.decay, h.b1, h.b2, h.eps, h.step_size, h.bc2_sqrt, float(lo), float(hi),
+                                    _ptr(max_abs_delta), _stream()), "adil_adamw_clamp")
+
+
+def adamw_l1ball_(v: Tensor, grad_vb: Tensor, pos: Optional[Tensor], m: Tensor, s: Tensor, h: AdamWScalars,
+                  radius: float, max_abs_delta: Optional[Tensor] = None) -> None:
+    """In-place AdamW on ALL rows of v (zero gradient outside the batch) + l1-ball projection
+    (adil.py:186-187; radius < 0 skips the projection)."""
+    lib = _lib.load()
+    for name, t in (("v", v), ("m", m), ("s", s), ("grad_vb", grad_vb)):
+        _dev(t, name, torch.float32)
+    n, k = v.shape
+    if pos is not None:
+        _dev(pos, "pos", torch.int32)
+        if pos.numel() != n:
+            raise ValueError("pos must have one entry per row of v")
+    elif grad_vb.shape[0] != n:
+        raise ValueError("without pos, grad_vb must have one row per row of v")
+    if grad_vb.shape[1] != k or m.shape != v.shape or s.shape != v.shape:
+        raise ValueError("adamw_l1ball_: shape mismatch")
+    if max_abs_delta is not None:
+        _dev(max_abs_delta, "max_abs_delta", torch.float32)
+    _lib.check(lib.adil_adamw_l1ball(_ptr(v), _ptr(grad_vb), _ptr(pos), _ptr(m), _ptr(s), n, k, h.decay, h.b1, h.b2,
+                                     h.eps, h.step_size, h.bc2_sqrt, float(radius), _ptr(max_abs_delta), _stream()),
+               "adil_adamw_l1ball")
+
+
+def l1ball_project_(x: Tensor, radius: float) -> Tensor:
+    """In-place row-wise projection onto the l1 ball (utils.py:21-41). x is (N, ...) fp32; rows are flattened."""
+    lib = _lib.load()
+    _dev(x, "x", torch.float32)
+    n = x.shape[0]
+    k = x.numel() // max(n, 1)
+    _lib.check(lib.adil_l1ball_project(_ptr(x), n, k, float(radius), _stream()), "adil_l1ball_project")
+    return x
+
+
+def l2ball_project_(x: Tensor, radius: float) -> Tensor:
+    lib = _lib.load()
+    _dev(x, "x", torch.float32)
+    n = x.shape[0]
+    _lib.check(lib.adil_l2ball_project(_ptr(x), n, x.numel() // max(n, 1), float(radius), _stream()),
+               "adil_l2ball_project")
+    return x
+
+
+def ista_step_(v: Tensor, g: Optional[Tensor], step: float, lam: float) -> Tensor:
+    """v = softshrink(v - step*g, lam) in place (adil_regularized.py:570-573)."""
+    lib = _lib.load()
+    _dev(v, "v", torch.float32)
+    if g is not None:
+        _dev(g, "g", torch.float32)
+        if g.numel() != v.numel():
+            raise ValueError("ista_step_: size mismatch")
+    _lib.check(lib.adil_ista_step(_ptr(v), _ptr(g), v.numel(), float(step), float(lam), _stream()), "adil_ista_step")
+    return v
+
+
+def atom_norms(d: Tensor) -> Tensor:
+    lib = _lib.load()
+    _dev(d, "d", torch.float32)
+    p, k = dict_shape(d)
+    nbytes = lib.adil_atom_workspace_bytes(p, k)
+    ws = _workspace(d.device, nbytes)
+    norms = torch.empty(k, dtype=torch.float32, device=d.device)
+    _lib.check(lib.adil_atom_norms(_ptr(d), p, k, _ptr(norms), _ptr(ws), nbytes, _stream()), "adil_atom_norms")
+    return norms
+
+
+def atom_l2_project_(d: Tensor, sphere: bool = False) -> Tensor:
+    """constraint_dict 'l2ball' / 'l2sphere' in place (utils.py:44-54)."""
+    lib = _lib.load()
+    norms = atom_norms(d)
+    p, k = dict_shape(d)
+    _lib.check(lib.adil_atom_scale(_ptr(d), p, k, _ptr(norms), int(bool(sphere)), _stream()), "adil_atom_scale")
+    return d
+
+
+def gram(d: Tensor) -> Tensor:
+    """D^T D (K x K) (adil.py:523)."""
+    lib = _lib.load()
+    _dev(d, "d", torch.float32)
+    p, k = dict_shape(d)
+    nbytes = lib.adil_gram_workspace_bytes(p, k)
+    ws = _workspace(d.device, nbytes)
+    out = torch.empty(k, k, dtype=torch.float32, device=d.device)
+    _lib.check(lib.adil_gram(_ptr(d), p, k, _ptr(out), _ptr(ws), nbytes, _stream()), "adil_gram")
+    return out
+
+
+def dict_rightmul(d: Tensor, mat: Tensor) -> Tensor:
+    """D M^T as a (C,H,W,K) tensor; with M = (DtD)^-1 this is D_dagger^T (adil.py:525)."""
+    lib = _lib.load()
+    _dev(d, "d", torch.float32)
+    _dev(mat, "mat", torch.float32)
+    p, k = dict_shape(d)
+    if mat.shape != (k, k):
+        raise ValueError("mat must be K x K")
+    out = torch.empty_like(d)
+    _lib.check(lib.adil_dict_rightmul(_ptr(d), _ptr(mat), p, k, _ptr(out), _stream()), "adil_dict_rightmul")
+    return out
+
+
+def image_metrics(adv: Tensor, x: Tensor) -> Tuple[Tensor, Tensor]:
+    """Per-image sum (adv-x)^2 and sum x^2 (performance.py:249-266)."""
+    lib = _lib.load()
+    _dev(adv, "adv")
+    _dev(x, "x", adv.dtype)
+    b = x.shape[0]
+    p = x.numel() // b
+    se = torch.empty(b, dtype=torch.float32, device=x.device)
+    sn = torch.empty(b, dtype=torch.float32, device=x.device)
+    _lib.check(lib.adil_image_metrics(_ptr(adv), _ptr(x), b, p, stream_dtype_code(x.dtype), _ptr(se), _ptr(sn),
+                                      _stream()), "adil_image_metrics")
+    return se, sn
+
+
+# --------------------------------------------------------------------------- #
+class DictSynthFunction(torch.autograd.Function):
+    """x + D v[index] as a differentiable op (the tensordot of adil.py:25 and its autograd backward).
+    grad wrt v is dense (N,K) with zero rows outside `index`, exactly what autograd produces."""
+
+    @staticmethod
+    def forward(ctx, x, d, v, index):
+        b = x.shape[0]
+        vp = pack_codes(v.detach(), index, b)
+        out = synth(x.detach().contiguous(), d.detach().contiguous(), vp, b)
+        ctx.save_for_backward(d.detach(), vp, index if index is not None else torch.empty(0))
+        ctx.meta = (b, v.shape, index is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        d, vp, index = ctx.saved_tensors
+        b, vshape, has_index = ctx.meta
+        need_x, need_d, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        g = g.contiguous()
+        grad_d, gvb = None, None
+        if need_d or need_v:
+            grad_d, gvb = grad(g, d.contiguous(), vp, b, want_d=need_d, want_v=need_v)
+        grad_v = None
+        if need_v:
+            grad_v = torch.zeros(vshape, dtype=torch.float32, device=g.device)
+            if has_index:
+                grad_v.index_add_(0, index.to(g.device), gvb)
+            else:
+                grad_v[:b] = gvb
+        return (g if need_x else None), grad_d, grad_v, None
+
+
+def dict_synth(x: Tensor, d: Tensor, v: Tensor, index: Optional[Tensor]) -> Tensor:
+    if index is not None and not isinstance(index, torch.Tensor):
+        index = torch.as_tensor(list(index), dtype=torch.int64)
+    if index is not None:
+        index = index.to(device=x.device, dtype=torch.int64)
+    return DictSynthFunction.apply(x, d, v, index)

@@ -1,0 +1,320 @@
+"""Frozen ImageNet classifiers for the ADiL CLIs and benchmarks, in plain torch.
+
+torchvision is not available in this image and pretrained weights are a network fetch, so the architectures the
+reference takes from torchvision (demo_dL_attack.py:41-53: resnet18, densenet121, mobilenet_v2, vgg11, ...) and
+the ones BASELINE.json names (ResNet-50, DenseNet-121, ViT-B/16) are defined here with torchvision-compatible
+parameter names: a torchvision state_dict on local disk loads with `weights=path`.  Without weights the networks
+are randomly initialised from a seed (synthetic throughput / plumbing runs).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Normalize(nn.Module):
+    """(x - mean) / std per channel, the wrapper both reference CLIs put in front of the network
+    (demo_dL_attack.py:16-25, main.py:15-24)."""
+
+    def __init__(self, mean, std):
+        super().__init__()
+        self.register_buffer('mean', torch.tensor(mean, dtype=torch.float32))
+        self.register_buffer('std', torch.tensor(std, dtype=torch.float32))
+
+    def forward(self, input):
+        mean = self.mean.reshape(1, 3, 1, 1).to(input.dtype)
+        std = self.std.reshape(1, 3, 1, 1).to(input.dtype)
+        return (input - mean) / std
+
+
+# ----------------------------------------------------------------------------- ResNet
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inp, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inp, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idt)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inp, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inp, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idt)
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, num_classes=1000):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make(block, 64, layers[0], 1)
+        self.layer2 = self._make(block, 128, layers[1], 2)
+        self.layer3 = self._make(block, 256, layers[2], 2)
+        self.layer4 = self._make(block, 512, layers[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+    def _make(self, block, planes, n, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                                 nn.BatchNorm2d(planes * block.expansion))
+        blocks = [block(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * block.expansion
+        blocks += [block(self.inplanes, planes) for _ in range(1, n)]
+        return nn.Sequential(*blocks)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+# ----------------------------------------------------------------------------- DenseNet-121
+class _DenseLayer(nn.Module):
+    def __init__(self, inp, growth=32, bn_size=4):
+        super().__init__()
+        self.norm1 = nn.BatchNorm2d(inp)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(inp, bn_size * growth, 1, bias=False)
+        self.norm2 = nn.BatchNorm2d(bn_size * growth)
+        self.relu2 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(bn_size * growth, growth, 3, 1, 1, bias=False)
+
+    def forward(self, feats):
+        x = torch.cat(feats, 1)
+        x = self.conv1(self.relu1(self.norm1(x)))
+        return self.conv2(self.relu2(self.norm2(x)))
+
+
+class _DenseBlock(nn.ModuleDict):
+    def __init__(self, n, inp, growth=32):
+        super().__init__()
+        for i in range(n):
+            self.add_module(f'denselayer{i + 1}', _DenseLayer(inp + i * growth, growth))
+
+    def forward(self, x):
+        feats = [x]
+        for layer in self.values():
+            feats.append(layer(feats))
+        return torch.cat(feats, 1)
+
+
+class DenseNet(nn.Module):
+    def __init__(self, block_config=(6, 12, 24, 16), growth=32, init_features=64, num_classes=1000):
+        super().__init__()
+        feats = OrderedDict([('conv0', nn.Conv2d(3, init_features, 7, 2, 3, bias=False)),
+                             ('norm0', nn.BatchNorm2d(init_features)), ('relu0', nn.ReLU(inplace=True)),
+                             ('pool0', nn.MaxPool2d(3, 2, 1))])
+        nf = init_features
+        for i, n in enumerate(block_config):
+            feats[f'denseblock{i + 1}'] = _DenseBlock(n, nf, growth)
+            nf += n * growth
+            if i != len(block_config) - 1:
+                feats[f'transition{i + 1}'] = nn.Sequential(OrderedDict([
+                    ('norm', nn.BatchNorm2d(nf)), ('relu', nn.ReLU(inplace=True)),
+                    ('conv', nn.Conv2d(nf, nf // 2, 1, bias=False)), ('pool', nn.AvgPool2d(2, 2))]))
+                nf //= 2
+        feats['norm5'] = nn.BatchNorm2d(nf)
+        self.features = nn.Sequential(feats)
+        self.classifier = nn.Linear(nf, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+
+    def forward(self, x):
+        x = F.relu(self.features(x), inplace=True)
+        return self.classifier(torch.flatten(F.adaptive_avg_pool2d(x, 1), 1))
+
+
+# ----------------------------------------------------------------------------- ViT-B/16
+class _MLPBlock(nn.Sequential):
+    def __init__(self, dim, hidden):
+        super().__init__(nn.Linear(dim, hidden), nn.GELU(), nn.Dropout(0.0), nn.Linear(hidden, dim), nn.Dropout(0.0))
+
+
+class _EncoderBlock(nn.Module):
+    def __init__(self, heads, dim, mlp_dim):
+        super().__init__()
+        self.ln_1 = nn.LayerNorm(dim, eps=1e-6)
+        self.self_attention = nn.MultiheadAttention(dim, heads, batch_first=True)
+        self.ln_2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _MLPBlock(dim, mlp_dim)
+
+    def forward(self, x):
+        y = self.ln_1(x)
+        y, _ = self.self_attention(y, y, y, need_weights=False)
+        x = x + y
+        return x + self.mlp(self.ln_2(x))
+
+
+class _Encoder(nn.Module):
+    def __init__(self, seq, layers, heads, dim, mlp_dim):
+        super().__init__()
+        self.pos_embedding = nn.Parameter(torch.empty(1, seq, dim).normal_(std=0.02))
+        self.layers = nn.Sequential(OrderedDict((f'encoder_layer_{i}', _EncoderBlock(heads, dim, mlp_dim))
+                                                for i in range(layers)))
+        self.ln = nn.LayerNorm(dim, eps=1e-6)
+
+    def forward(self, x):
+        return self.ln(self.layers(x + self.pos_embedding))
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, image_size=224, patch=16, layers=12, heads=12, dim=768, mlp_dim=3072, num_classes=1000):
+        super().__init__()
+        self.patch, self.dim = patch, dim
+        self.conv_proj = nn.Conv2d(3, dim, patch, patch)
+        self.class_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.encoder = _Encoder((image_size // patch) ** 2 + 1, layers, heads, dim, mlp_dim)
+        self.heads = nn.Sequential(OrderedDict([('head', nn.Linear(dim, num_classes))]))
+
+    def forward(self, x):
+        n = x.shape[0]
+        x = self.conv_proj(x).reshape(n, self.dim, -1).permute(0, 2, 1)
+        x = torch.cat([self.class_token.expand(n, -1, -1), x], dim=1)
+        return self.heads(self.encoder(x)[:, 0])
+
+
+# ----------------------------------------------------------------------------- MobileNetV2 / VGG11
+class _ConvBNReLU6(nn.Sequential):
+    def __init__(self, inp, out, k=3, stride=1, groups=1):
+        super().__init__(nn.Conv2d(inp, out, k, stride, (k - 1) // 2, groups=groups, bias=False),
+                         nn.BatchNorm2d(out), nn.ReLU6(inplace=True))
+
+
+class _InvertedResidual(nn.Module):
+    def __init__(self, inp, out, stride, expand):
+        super().__init__()
+        hidden = int(round(inp * expand))
+        self.use_res = stride == 1 and inp == out
+        layers = []
+        if expand != 1:
+            layers.append(_ConvBNReLU6(inp, hidden, 1))
+        layers += [_ConvBNReLU6(hidden, hidden, 3, stride, hidden), nn.Conv2d(hidden, out, 1, bias=False),
+                   nn.BatchNorm2d(out)]
+        self.conv = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return x + self.conv(x) if self.use_res else self.conv(x)
+
+
+class MobileNetV2(nn.Module):
+    def __init__(self, num_classes=1000):
+        super().__init__()
+        cfg = [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1)]
+        feats = [_ConvBNReLU6(3, 32, 3, 2)]
+        inp = 32
+        for t, c, n, s in cfg:
+            for i in range(n):
+                feats.append(_InvertedResidual(inp, c, s if i == 0 else 1, t))
+                inp = c
+        feats.append(_ConvBNReLU6(inp, 1280, 1))
+        self.features = nn.Sequential(*feats)
+        self.classifier = nn.Sequential(nn.Dropout(0.2), nn.Linear(1280, num_classes))
+
+    def forward(self, x):
+        x = F.adaptive_avg_pool2d(self.features(x), 1)
+        return self.classifier(torch.flatten(x, 1))
+
+
+class VGG11(nn.Module):
+    def __init__(self, num_classes=1000):
+        super().__init__()
+        layers, inp = [], 3
+        for v in (64, 'M', 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512, 'M'):
+            if v == 'M':
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(inp, v, 3, padding=1), nn.ReLU(inplace=True)]
+                inp = v
+        self.features = nn.Sequential(*layers)
+        self.avgpool = nn.AdaptiveAvgPool2d(7)
+        self.classifier = nn.Sequential(nn.Linear(512 * 49, 4096), nn.ReLU(True), nn.Dropout(), nn.Linear(4096, 4096),
+                                        nn.ReLU(True), nn.Dropout(), nn.Linear(4096, num_classes))
+
+    def forward(self, x):
+        return self.classifier(torch.flatten(self.avgpool(self.features(x)), 1))
+
+
+# ----------------------------------------------------------------------------- registry
+_BUILDERS = {
+    'resnet18': lambda nc: ResNet(BasicBlock, [2, 2, 2, 2], nc),
+    'resnet50': lambda nc: ResNet(Bottleneck, [3, 4, 6, 3], nc),
+    'densenet121': lambda nc: DenseNet(num_classes=nc),
+    'vit_b_16': lambda nc: VisionTransformer(num_classes=nc),
+    'mobilenet_v2': lambda nc: MobileNetV2(nc),
+    'vgg11': lambda nc: VGG11(nc),
+}
+# names accepted by the reference CLIs (demo_dL_attack.py:41-53) and the BASELINE.json config names
+ALIASES = {'resnet': 'resnet18', 'densenet': 'densenet121', 'mobilenet': 'mobilenet_v2', 'vgg': 'vgg11',
+           'vit': 'vit_b_16', 'vit-b/16': 'vit_b_16', 'resnet-50': 'resnet50', 'densenet-121': 'densenet121'}
+UNSUPPORTED = {'googlenet': 'GoogLeNet', 'inception': 'Inception-v3'}
+
+
+def canonical_name(name: str) -> str:
+    key = name.lower()
+    key = ALIASES.get(key, key)
+    if key in UNSUPPORTED:
+        raise NotImplementedError(f"{UNSUPPORTED[key]} is not defined in this build (no torchvision here); "
+                                  f"available: {sorted(_BUILDERS)}")
+    if key not in _BUILDERS:
+        raise ValueError(f"unknown model {name!r}; available: {sorted(_BUILDERS) + sorted(ALIASES)}")
+    return key
+
+
+def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights: Optional[str] = None,
+                     device=None, dtype: torch.dtype = torch.float32, channels_last: bool = False) -> nn.Module:
+    """Sequential(Normalize, net), eval mode, parameters frozen — the object both CLIs hand to ADIL."""
+    key = canonical_name(name)
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(seed)
+        net = _BUILDERS[key](num_classes)
+    if weights is not None:
+        net.load_state_dict(torch.load(weights, map_location='cpu'))
+    model = nn.Sequential(Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225]), net)
+    model.eval()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    model = model.to(device=device, dtype=dtype)
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    return model

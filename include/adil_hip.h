@@ -1,0 +1,128 @@
+/*
+ * adil_hip.h — C ABI of libadil_hip.so, the MI355X (gfx950) kernels of the ADiL
+ * (Adversarial Dictionary Learning) attack hot path.
+ *
+ * The upstream reference (flavie-yuan-liu/DL_attack_on_ImageNet) is pure Python on
+ * PyTorch: it has no FFI.  Each entry point below replaces a *sequence of torch
+ * ops* on the reference's hot path; the reference interface it replaces is cited
+ * as file:line.  INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; the library keeps no
+ *     state and allocates nothing persistent; scratch comes in through `ws`.
+ *   - `stream` is the caller's hipStream_t (as void*; 0 = default stream).
+ *     Kernels are launched asynchronously on it; nothing synchronises.
+ *   - return value: 0 on success, otherwise a hipError_t value or one of the
+ *     ADIL_E* codes (< 0).  Nothing throws across the boundary.
+ *   - the dictionary D is the reference's (C,H,W,K) fp32 tensor, i.e. a
+ *     row-major P x K matrix, P = C*H*W, atom index innermost (adil.py:20,25).
+ *   - image-shaped streams (x, x_adv, g, z) are row-major B x P, element type
+ *     chosen by `dtype` (ADIL_F32 or ADIL_BF16); codes V are fp32 N x K.
+ *   - "packed codes": vp is [Bp][Kp] fp32 with Bp = roundup(B,32),
+ *     Kp = roundup(K,16), zero padded (see adil_pack_codes).
+ */
+#ifndef ADIL_HIP_H
+#define ADIL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADIL_F32 0
+#define ADIL_BF16 1
+
+#define ADIL_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported K) */
+#define ADIL_EWORKSPACE (-2) /* workspace too small */
+
+/* ABI version of this header; bumped on any signature change. */
+int adil_abi_version(void);
+
+/* Largest K (atoms) the kernels support. */
+int adil_max_atoms(void);
+
+/* Bytes of scratch adil_grad needs for this problem size. */
+size_t adil_grad_workspace_bytes(int B, int P, int K);
+
+/* Gather + pad the batch's code rows:  vp[b][k] = v[index[b]][k] (0 for k>=K, b>=B).
+ * Replaces the advanced-indexing `self.v[index, :]` of Attack_dict_model.forward
+ * (adil.py:25).  index may be NULL (rows 0..B-1, as adil.py:600 `range(n_img)`). */
+int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, void* stream);
+
+/* Perturbation synthesis, fused with the add and the optional clamps:
+ *     delta = vp D^T ;  delta = clamp(delta, -delta_clamp, +delta_clamp)   if delta_clamp >= 0
+ *     out   = x + delta ;  out = clamp(out, 0, 1)                          if pixel_clamp
+ * x may be NULL (out = delta).  Replaces `tensordot(v[index,:], d, ([1],[3]))` + `x + dv`
+ * (adil.py:25-26, :543-544, :617), the per-image loop of forward_unsupervised with
+ * its +-eps clamp (adil.py:480-484) and the final [0,1] clamp (adil.py:567, :623). */
+int adil_synth(const void* x, const float* d, const float* vp, void* out, int B, int P, int K, int dtype,
+               float delta_clamp, int pixel_clamp, void* stream);
+
+/* Adjoint of the synthesis in ONE pass over the upstream gradient g = dLoss/d(x+delta):
+ *     grad_d  (P x K)  = g^T vp          if grad_d  != NULL   (accumulated into grad_d when accumulate_d)
+ *     grad_vb (B x K)  = g D             if grad_vb != NULL
+ * Replaces autograd's backward of the tensordot at adil.py:25 (loss.backward(), adil.py:185,
+ * :281, :308, :606) and the forward contraction `tensordot(z, d_drg, ([1,2,3],[1,2,3]))`
+ * (adil.py:542, :563) when called with g := z and d := D_dagger^T (grad_vb only). */
+int adil_grad(const void* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P, int K,
+              int dtype, int accumulate_d, void* ws, size_t ws_bytes, void* stream);
+
+/* Fused AdamW step + box projection on a flat fp32 parameter (torch.optim.AdamW semantics):
+ *     p *= decay ; m += (1-b1)(g-m) ; s = b2 s + (1-b2) g^2 ;
+ *     p -= step_size * m / (sqrt(s)/bc2_sqrt + eps) ;  p = clamp(p, lo, hi)
+ * decay = 1-lr*wd, step_size = lr/(1-b1^t), bc2_sqrt = sqrt(1-b2^t) are computed by the caller in
+ * double, exactly as torch does.  g has element type g_dtype.  If max_abs_delta != NULL,
+ * atomically maxes |p_new - p_old| into it (a float the caller zeroed).
+ * Replaces optimise.step() + update_d (adil.py:186,188 with :33-35; clamp [-1,1]) and
+ * optimise.step() + the z clamp (adil.py:554-555, :559; clamp [-eps,eps]). */
+int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, float* s, size_t n, float decay, float b1,
+                     float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi,
+                     float* max_abs_delta, void* stream);
+
+/* Fused AdamW step on ALL N rows of the code matrix + row-wise l1-ball projection.
+ * The gradient is non-zero only for the rows of the current batch: pos[n] = b if row n is
+ * batch slot b (gradient row grad_vb[b]), -1 otherwise (zero gradient; the row still
+ * moves through momentum and weight decay — reference quirk Q3).  pos may be NULL
+ * (row n <-> grad_vb[n], N == B).  radius < 0 skips the projection.
+ * Replaces optimise.step() + update_v (adil.py:186-187 with :29-31 and utils.py:21-41),
+ * and the same pair in forward_supervised_AdamW (adil.py:609-610, :614). */
+int adil_adamw_l1ball(float* v, const float* grad_vb, const int32_t* pos, float* m, float* s, int N, int K,
+                      float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt, float radius,
+                      float* max_abs_delta, void* stream);
+
+/* Row-wise Euclidean projection onto the l1 ball, in place: project_onto_l1_ball (utils.py:21-41). */
+int adil_l1ball_project(float* x, int N, int K, float radius, void* stream);
+
+/* Row-wise projection onto the l2 ball: x_i *= radius / max(||x_i||_2, radius) (adil.py:626-629). */
+int adil_l2ball_project(float* x, int N, int K, float radius, void* stream);
+
+/* ISTA step: v = softshrink(v - step * g, lam)   (g may be NULL: plain softshrink).
+ * Replaces Softshrink(step*lambda)(v - step*grad_v) (adil_regularized.py:141-144, :304,
+ * :414-416, :570-573; utils.py:159-161). */
+int adil_ista_step(float* v, const float* g, size_t n, float step, float lam, void* stream);
+
+/* Per-atom Frobenius norms of D: norms[k] = ||D[:,k]||_2   (utils.py:48). ws: adil_atom_workspace_bytes. */
+size_t adil_atom_workspace_bytes(int P, int K);
+int adil_atom_norms(const float* d, int P, int K, float* norms, void* ws, size_t ws_bytes, void* stream);
+
+/* Per-atom scaling: d[:,k] /= (sphere ? norms[k] : max(norms[k], 1))   (utils.py:49-54). */
+int adil_atom_scale(float* d, int P, int K, const float* norms, int sphere, void* stream);
+
+/* Gram matrix  gram (K x K) = D^T D   (adil.py:523). ws: adil_atom_workspace_bytes(P, K*K)… see .hip */
+size_t adil_gram_workspace_bytes(int P, int K);
+int adil_gram(const float* d, int P, int K, float* gram, void* ws, size_t ws_bytes, void* stream);
+
+/* out (P x K) = D M^T  with M (K x K):  D_dagger^T = D (DtD^-1)^T   (adil.py:525, stored P x K). */
+int adil_dict_rightmul(const float* d, const float* mat, int P, int K, float* out, void* stream);
+
+/* Per-image evaluation sums (performance.py:249-266): sq_err[b] = sum_p (adv-x)^2, sq_norm[b] = sum_p x^2. */
+int adil_image_metrics(const void* adv, const void* x, int B, int P, int dtype, float* sq_err, float* sq_norm,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADIL_HIP_H */

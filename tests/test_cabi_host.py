@@ -1,0 +1,177 @@
+"""CPU: the C-ABI library loads and exports every symbol include/adil_hip.h declares (no compute calls without a
+GPU), the ctypes table mirrors the header, the product refuses to run on CPU tensors, and the host-side logic
+(AdamW scalars, sharding, hyper-parameter grid, CLI flags, model zoo, dataset protocol) behaves."""
+import ctypes
+import math
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "adil_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(adil_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dl_attack_on_imagenet_amd import _lib
+    from dl_attack_on_imagenet_amd.build import build_library
+    build_library(verbose=False)
+    lib = ctypes.CDLL(_lib.LIBPATH)
+    syms = header_symbols()
+    assert len(syms) >= 18
+    for name in syms:
+        assert hasattr(lib, name), f"{name} declared in adil_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms            # binding table and header agree
+    bound = _lib.load()
+    assert bound.adil_abi_version() == _lib.ABI_VERSION
+    assert bound.adil_max_atoms() == 128
+    assert bound.adil_grad_workspace_bytes(512, 150528, 50) > 0
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from dl_attack_on_imagenet_amd import _lib
+    with pytest.raises(_lib.AdilLibraryError):
+        _lib.load(str(tmp_path / "nope.so"))
+
+
+def test_product_has_no_cpu_fallback():
+    from dl_attack_on_imagenet_amd import ops
+    from attacks.utils import project_onto_l1_ball
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.l1ball_project_(torch.zeros(3, 4), 0.1)
+    with pytest.raises(RuntimeError):
+        project_onto_l1_ball(torch.zeros(3, 4), 0.1)
+    with pytest.raises(RuntimeError):
+        ops.pack_codes(torch.zeros(3, 4), None, 3)
+
+
+def test_product_never_imports_the_oracle():
+    for base in ("dl_attack_on_imagenet_amd", "attacks"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith(".py"):
+                    assert "oracle" not in open(os.path.join(dirpath, f)).read(), os.path.join(dirpath, f)
+    for f in ("performance.py", "demo_dL_attack.py", "main.py", "imagenet_loading.py"):
+        assert "oracle" not in open(os.path.join(ROOT, f)).read(), f
+
+
+def test_adamw_schedule_matches_torch():
+    from dl_attack_on_imagenet_amd.ops import AdamWSchedule
+    from oracle.adil_oracle import AdamWState
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(257, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=0.01)
+    sch = AdamWSchedule(0.01)
+    p = p0.clone()
+    st = AdamWState(p, 0.01)
+    m, s = torch.zeros_like(p0), torch.zeros_like(p0)
+    q = p0.clone()
+    for _ in range(4):
+        grad = torch.randn(257, generator=g)
+        ref.grad = grad.clone()
+        opt.step()
+        st.step(p, grad)
+        h = sch.next()                               # the scalars handed to the kernel, applied in plain torch
+        q = q * h.decay
+        m = m + (1 - h.b1) * (grad - m)
+        s = s * h.b2 + (1 - h.b2) * grad * grad
+        q = q - h.step_size * (m / (s.sqrt() / h.bc2_sqrt + h.eps))
+        assert float((ref.data - p).abs().max()) < 1e-6
+        assert float((ref.data - q).abs().max()) < 1e-6
+    assert sch.t == 4 and math.isclose(h.step_size, 0.01 / (1 - 0.9 ** 4))
+
+
+def test_shard_bounds_cover_and_balance():
+    from dl_attack_on_imagenet_amd.dist import shard_batch, shard_bounds
+    for n in (1, 7, 512, 4096, 10001):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_batch(list(range(10)), 1, 4) == [3, 4, 5]
+
+
+def test_get_args_grid_and_slices():
+    import performance as perf
+    from attacks.utils import get_slices
+    assert perf.get_args(()) == [{}]
+    assert perf.get_args(("a", [1, 2])) == [{"a": 1}, {"a": 2}]
+    grid = perf.get_args(("a", [1, 2], "b", [3], "c", [4, 5]))
+    assert grid == [{"a": 1, "b": 3, "c": 4}, {"a": 1, "b": 3, "c": 5}, {"a": 2, "b": 3, "c": 4}, {"a": 2, "b": 3, "c": 5}]
+    assert get_slices(7, 3) == [[0, 1, 2], [3, 4, 5], [6]]
+    assert get_slices(0, 3) == []
+
+
+def test_cli_flags_match_reference():
+    import demo_dL_attack
+    import main as main_cli
+    a = demo_dL_attack.build_parser().parse_args([])
+    assert (a.model, a.seed, a.num_train_per_class, a.trained_classes, a.distributed, a.gpu, a.steps_inference) == \
+        ("mobilenet", 3, 1, 1000, False, 0, 100)
+    a = demo_dL_attack.build_parser().parse_args(["-m", "densenet", "-s", "5", "--steps-inference", "30"])
+    assert (a.model, a.seed, a.steps_inference) == ("densenet", 5, 30)
+    assert main_cli.build_parser().parse_args([]).model == "mobilenet"
+    assert demo_dL_attack.main(a) is None            # no GPU here: returns early like the reference
+
+
+def test_zoo_names_and_shapes():
+    from dl_attack_on_imagenet_amd import zoo
+    assert zoo.canonical_name("resnet") == "resnet18" and zoo.canonical_name("DenseNet") == "densenet121"
+    assert zoo.canonical_name("mobilenet") == "mobilenet_v2" and zoo.canonical_name("vgg") == "vgg11"
+    with pytest.raises(NotImplementedError):
+        zoo.canonical_name("googlenet")
+    with pytest.raises(ValueError):
+        zoo.canonical_name("alexnet")
+    for name, nparam in (("resnet18", 11689512), ("resnet50", 25557032), ("densenet121", 7978856)):
+        m = zoo.build_classifier(name, seed=1)
+        assert sum(p.numel() for p in m[1].parameters()) == nparam          # torchvision-compatible definitions
+        assert not any(p.requires_grad for p in m.parameters()) and not m.training
+    y = zoo.build_classifier("resnet18", num_classes=7, seed=1)(torch.rand(2, 3, 64, 64))
+    assert y.shape == (2, 7)
+    a = zoo.build_classifier("resnet18", seed=3)[1].fc.weight
+    b = zoo.build_classifier("resnet18", seed=3)[1].fc.weight
+    assert torch.equal(a, b)
+
+
+def test_dataset_protocol_and_split():
+    import random
+    from imagenet_loading import Subset_I, SyntheticImageNet, dataset_split_by_class
+    ds = SyntheticImageNet(num_classes=4, samples_per_class=50, size=8, seed=1)
+    random.seed(0)
+    tr, va, te = dataset_split_by_class(ds, [3, 2, 5], number_of_classes=4)
+    assert (len(tr), len(va), len(te)) == (12, 8, 20)
+    assert not (set(tr.indices) & set(va.indices)) and not (set(va.indices) & set(te.indices))
+    labels = sorted(ds.samples[i][1] for i in tr.indices)
+    assert labels == [0] * 3 + [1] * 3 + [2] * 3 + [3] * 3                   # class balanced
+    x, y = tr[0]
+    assert x.shape == (3, 8, 8) and 0 <= float(x.min()) and float(x.max()) < 1
+    tr.indexed = True
+    i, x2, y2 = tr[0]
+    assert i == 0 and torch.equal(x, x2) and y == y2
+    assert isinstance(tr, Subset_I)
+
+
+def test_adil_constructor_surface_without_data(tmp_path):
+    from attacks import ADIL, ADILR, FastUAP, UAPPGD
+    net = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(12, 3))
+    atk = ADIL(net, eps=8 / 255, model_name="none", alpha=0.0, dict_dir=str(tmp_path))      # alpha accepted (Q14)
+    assert atk.model_file.endswith("ImageNet_none.bin") and atk.n_atoms == 100 and atk.loss == "ce"
+    assert atk.attack == "supervised" and atk.steps_inference == 30 and atk.norm == "linf"
+    assert atk.device == torch.device("cpu") and "ADIL" in str(atk)
+    with pytest.raises(FileNotFoundError):
+        atk(torch.zeros(1, 3, 2, 2), torch.zeros(1, dtype=torch.long))
+    for cls in (ADILR, FastUAP, UAPPGD):
+        with pytest.raises(NotImplementedError):
+            cls(net)
+    lg = torch.tensor([[1.0, 3.0, -2.0], [-1.0, -3.0, -2.0]])
+    out = atk.f_loss(lg, torch.tensor([1, 0]))
+    assert out.tolist() == [2.0, -1.0]               # second row: other logits negative -> max is the zeroed label (Q5)

@@ -1,0 +1,271 @@
+"""GPU parity: every C-ABI kernel (through ctypes, dl_attack_on_imagenet_amd.ops) against the oracle on the same
+seeded inputs and against the golden vectors.  fp32 paths: tolerances are absolute fp32 rounding bounds written
+per test; bf16 stream paths: compared with an fp32 oracle evaluated on the bf16-rounded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, t
+from oracle import adil_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def ops():
+    from dl_attack_on_imagenet_amd import ops as _ops
+    return _ops
+
+
+def close(a, b, tol, what=""):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b).detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = float((a - b).abs().max()) if a.numel() else 0.0
+    assert err <= tol, (what, err, tol)
+
+
+def test_library_loaded_and_abi():
+    from dl_attack_on_imagenet_amd import _lib
+    lib = _lib.load()
+    assert lib.adil_abi_version() == _lib.ABI_VERSION
+    assert lib.adil_max_atoms() >= 128
+
+
+# ----------------------------------------------------------------------------- projections / prox
+def test_l1ball_golden():
+    z = load_golden("g1_l1ball")
+    for tag in "abcde":
+        x = t(z[f"x_{tag}"], DEV).contiguous()
+        y = ops().l1ball_project_(x.clone(), float(z["eps"]))
+        close(y, z[f"y_{tag}"], 2e-7, f"l1ball {tag}")
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (3, 2), (257, 10), (1000, 50), (513, 64), (300, 65), (200, 100), (64, 128)])
+def test_l1ball_random(n, k):
+    g = torch.Generator().manual_seed(n * 131 + k)
+    x = torch.randn(n, k, generator=g) * 0.03
+    x[::7] *= 0.01                        # rows inside the ball
+    x[1::11] = 0.0                        # zero rows
+    eps = 8 / 255
+    y = ops().l1ball_project_(x.to(DEV), eps)
+    ref = O.project_onto_l1_ball(x, eps)
+    close(y, ref, 3e-7)
+    l1 = y.abs().sum(1).cpu()
+    assert float(l1.max()) <= eps * (1 + 1e-5)
+    # idempotence (size-independent property)
+    close(ops().l1ball_project_(y.clone(), eps), y, 3e-7)
+
+
+def test_l2ball_and_constraints_golden():
+    z = load_golden("g2_constraints")
+    eps = float(z["eps"])
+    close(ops().l2ball_project_(t(z["v"], DEV).clone(), eps), z["pv_l2"], 1e-7)
+    close(ops().l1ball_project_(t(z["v"], DEV).clone(), eps), z["pv_linf"], 2e-7)
+    close(ops().atom_l2_project_(t(z["d"], DEV).clone(), sphere=False), z["l2ball"], 2e-7)
+    close(ops().atom_l2_project_(t(z["d"], DEV).clone(), sphere=True), z["l2sphere"], 2e-7)
+
+
+def test_softshrink_golden_and_ista():
+    z = load_golden("g3_softshrink")
+    close(ops().ista_step_(t(z["x"], DEV).clone(), None, 0.0, float(z["lam"])), z["y"], 0)
+    g = torch.Generator().manual_seed(3)
+    v, gr = torch.randn(37, 50, generator=g) * 0.1, torch.randn(37, 50, generator=g)
+    out = ops().ista_step_(v.to(DEV), gr.to(DEV), 0.05, 0.02)
+    close(out, O.softshrink(v - 0.05 * gr, 0.02), 1e-7)
+
+
+# ----------------------------------------------------------------------------- contractions
+def _oracle_synth(x, d, vrows, delta_clamp=None, pixel_clamp=False):
+    dv = (vrows @ O.dict_matrix(d).t()).reshape(x.shape)
+    if delta_clamp is not None:
+        dv = dv.clamp(-delta_clamp, delta_clamp)
+    out = x + dv
+    return out.clamp(0, 1) if pixel_clamp else out
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_synth_grad_golden(tag):
+    z = load_golden("g4_synth_grad")
+    d, v, x, idx, g = (t(z[f"{n}_{tag}"], DEV) for n in ("d", "v", "x", "index", "g"))
+    b = x.shape[0]
+    vp = ops().pack_codes(v, idx, b)
+    close(ops().synth(x, d, vp, b), z[f"y_{tag}"], 2e-6)
+    gd, gvb = ops().grad(g, d, vp, b)
+    close(gd, z[f"grad_d_{tag}"], 2e-5)
+    gv = torch.zeros_like(v)
+    gv[idx] = gvb
+    close(gv, z[f"grad_v_{tag}"], 2e-4)
+    # the autograd wrapper must give the same thing (this is what Attack_dict_model.forward uses)
+    dd, vv = d.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    ops().dict_synth(x, dd, vv, idx).backward(g)
+    close(dd.grad, z[f"grad_d_{tag}"], 2e-5)
+    close(vv.grad, z[f"grad_v_{tag}"], 2e-4)
+
+
+SHAPES = [  # (B, C, H, W, K): ragged batch / pixel tails, K = 1 .. 128
+    (1, 3, 4, 4, 1), (5, 3, 7, 9, 3), (33, 3, 16, 16, 10), (64, 3, 20, 12, 50), (31, 1, 13, 17, 64),
+    (40, 3, 8, 8, 100), (17, 3, 10, 10, 128), (96, 3, 32, 32, 16),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_synth_random_f32(shape):
+    b, c, h, w, k = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    d = -1 + 2 * torch.rand(c, h, w, k, generator=g)
+    v = torch.randn(b + 3, k, generator=g) * 0.02
+    idx = torch.randperm(b + 3, generator=g)[:b]
+    x = torch.rand(b, c, h, w, generator=g)
+    vp = ops().pack_codes(v.to(DEV), idx.to(DEV), b)
+    close(vp[:b, :k], v[idx], 0)
+    assert float(vp[b:].abs().sum()) == 0 and float(vp[:, k:].abs().sum()) == 0
+    out = ops().synth(x.to(DEV), d.to(DEV), vp, b)
+    close(out, _oracle_synth(x, d, v[idx]), 1e-5 * max(1, k ** 0.5))
+    out = ops().synth(x.to(DEV), d.to(DEV), vp, b, delta_clamp=0.01, pixel_clamp=True)
+    close(out, _oracle_synth(x, d, v[idx], 0.01, True), 1e-5 * max(1, k ** 0.5))
+    only = ops().synth(None, d.to(DEV), vp, b, out_shape=x.shape, out_dtype=torch.float32)
+    close(only, _oracle_synth(torch.zeros_like(x), d, v[idx]), 1e-5 * max(1, k ** 0.5))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_grad_random_f32(shape):
+    b, c, h, w, k = shape
+    gen = torch.Generator().manual_seed(sum(shape) + 1)
+    d = -1 + 2 * torch.rand(c, h, w, k, generator=gen)
+    v = torch.randn(b, k, generator=gen) * 0.02
+    g = torch.randn(b, c, h, w, generator=gen)
+    vp = ops().pack_codes(v.to(DEV), None, b)
+    gd, gvb = ops().grad(g.to(DEV), d.to(DEV), vp, b)
+    rd, rv = O.grad_dv(g.double(), d.double(), v.double())
+    p = c * h * w
+    close(gd, rd, 2e-6 * b ** 0.5 * 4)                 # |g|~1, |v|~0.02, sum over B terms
+    close(gvb, rv, 3e-6 * p ** 0.5 * 4)                # |g|~1, |d|<=1, sum over P terms
+    # want_d / want_v individually, and accumulation into grad_d
+    gd2, none = ops().grad(g.to(DEV), d.to(DEV), vp, b, want_v=False)
+    assert none is None
+    close(gd2, gd, 0)
+    acc = gd.clone()
+    ops().grad(g.to(DEV), d.to(DEV), vp, b, want_v=False, grad_d=acc, accumulate_d=True)
+    close(acc, 2 * gd, 1e-6)
+    none, gv2 = ops().grad(g.to(DEV), d.to(DEV), None, b, want_d=False)
+    close(gv2, gvb, 0)
+
+
+@pytest.mark.parametrize("shape", [(33, 3, 16, 16, 10), (64, 3, 20, 12, 50), (40, 3, 8, 8, 100)])
+def test_synth_grad_bf16_streams(shape):
+    """bf16 image streams, fp32 D / V / accumulation: compare with the fp32 oracle on bf16-rounded inputs."""
+    b, c, h, w, k = shape
+    gen = torch.Generator().manual_seed(sum(shape) + 2)
+    d = -1 + 2 * torch.rand(c, h, w, k, generator=gen)
+    v = torch.randn(b, k, generator=gen) * 0.02
+    x = torch.rand(b, c, h, w, generator=gen).bfloat16()
+    g = torch.randn(b, c, h, w, generator=gen).bfloat16()
+    vp = ops().pack_codes(v.to(DEV), None, b)
+    out = ops().synth(x.to(DEV), d.to(DEV), vp, b)
+    assert out.dtype == torch.bfloat16
+    ref = _oracle_synth(x.float(), d, v)
+    close(out.float(), ref.bfloat16().float(), 2 ** -7)     # one bf16 ulp at magnitude <= 2
+    gd, gvb = ops().grad(g.to(DEV), d.to(DEV), vp, b)
+    rd, rv = O.grad_dv(g.double(), d.double(), v.double())
+    close(gd, rd, 1e-5 * b ** 0.5 * 4)
+    close(gvb, rv, 1e-5 * (c * h * w) ** 0.5 * 4)
+
+
+def test_linearity_full_size():
+    """Size-independent property at the BASELINE image size (P = 150528): the adjoint identity
+    <g, synth(0,D,V)> == <grad_d, D-direction> ... here: <g, D v> == <grad_vb, v> == <grad_d, 1 (x) v> checks."""
+    b, k = 48, 50
+    gen = torch.Generator().manual_seed(9)
+    d = (-1 + 2 * torch.rand(3, 224, 224, k, generator=gen)).to(DEV)
+    v = (torch.randn(b, k, generator=gen) * 0.02).to(DEV)
+    g = torch.randn(b, 3, 224, 224, generator=gen).to(DEV)
+    vp = ops().pack_codes(v, None, b)
+    dv = ops().synth(None, d, vp, b, out_shape=g.shape, out_dtype=torch.float32)
+    gd, gvb = ops().grad(g, d, vp, b)
+    lhs = float((g.double() * dv.double()).sum())
+    assert abs(lhs - float((gvb.double() * v.double()).sum())) <= 1e-4 * abs(lhs) + 1e-3
+    assert abs(lhs - float((gd.double() * d.double()).sum())) <= 1e-4 * abs(lhs) + 1e-3
+    # and against a torch fp64 matmul on the device
+    ref_dv = (v.double() @ d.reshape(-1, k).double().t()).reshape(g.shape)
+    close(dv, ref_dv, 2e-5)
+    close(gvb, g.reshape(b, -1).double() @ d.reshape(-1, k).double(), 2e-2)
+    close(gd.reshape(-1, k), g.reshape(b, -1).double().t() @ v.double(), 2e-5)
+
+
+# ----------------------------------------------------------------------------- optimiser
+def test_adamw_steps_golden():
+    """T steps of {AdamW(d,v); l1-ball(v); clamp(d)} against the reference's torch.optim.AdamW trajectory (G6)."""
+    z = load_golden("g6_adamw_steps")
+    eps, lr = float(z["eps"]), float(z["lr"])
+    d, v = t(z["d0"], DEV).clone(), t(z["v0"], DEV).clone()
+    md, sd, mv, sv = torch.zeros_like(d), torch.zeros_like(d), torch.zeros_like(v), torch.zeros_like(v)
+    sched_d, sched_v = ops().AdamWSchedule(lr), ops().AdamWSchedule(lr)
+    pos = torch.empty(v.shape[0], dtype=torch.int32, device=DEV)
+    for step in range(z["g"].shape[0]):
+        idx = t(z["index"][step], DEV)
+        b = idx.numel()
+        vp = ops().pack_codes(v, idx, b)
+        gd, gvb = ops().grad(t(z["g"][step], DEV), d, vp, b)
+        pos.fill_(-1)
+        pos[idx] = torch.arange(b, dtype=torch.int32, device=DEV)
+        ops().adamw_clamp_(d, gd, md, sd, sched_d.next(), -1.0, 1.0)
+        ops().adamw_l1ball_(v, gvb, pos, mv, sv, sched_v.next(), eps)
+        close(d, z["d_hist"][step], 5e-6, f"d step {step}")
+        close(v, z["v_hist"][step], 5e-6, f"v step {step}")
+    close(md, z["m_d"], 1e-5); close(sd, z["s_d"], 1e-5)
+    close(mv, z["m_v"], 1e-5); close(sv, z["s_v"], 1e-5)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 150528 * 3 + 2])
+@pytest.mark.parametrize("gdtype", [torch.float32, torch.bfloat16])
+def test_adamw_clamp_vs_torch(n, gdtype):
+    gen = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=gen)
+    gs = [torch.randn(n, generator=gen).to(gdtype) for _ in range(3)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=0.01)
+    p = p0.clone().to(DEV)
+    # device buffers from a 16-byte aligned allocation
+    m, s = torch.zeros_like(p), torch.zeros_like(p)
+    sched = ops().AdamWSchedule(0.01)
+    delta = torch.zeros(1, device=DEV)
+    for g in gs:
+        prev = ref.data.clone()
+        ref.grad = g.float()
+        opt.step()
+        ref.data.clamp_(-0.5, 0.5)
+        delta.zero_()
+        ops().adamw_clamp_(p, g.to(DEV), m, s, sched.next(), -0.5, 0.5, max_abs_delta=delta)
+        close(p, ref.data, 2e-6)
+        assert abs(float(delta) - float((ref.data - prev).abs().max())) <= 2e-6
+
+
+def test_gram_pinv():
+    gen = torch.Generator().manual_seed(5)
+    for (c, h, w, k) in [(3, 16, 16, 6), (3, 30, 21, 50), (3, 9, 9, 100)]:
+        d = (-1 + 2 * torch.rand(c, h, w, k, generator=gen))
+        dtd, dtd_inv, d_drg = O.gram_pinv(d.double())
+        gm = ops().gram(d.to(DEV))
+        close(gm, dtd, 1e-5 * (c * h * w) ** 0.5)
+        out = ops().dict_rightmul(d.to(DEV), dtd_inv.float().to(DEV))
+        close(out.reshape(-1, k), d_drg.reshape(k, -1).t(), 1e-5)
+
+
+def test_image_metrics():
+    gen = torch.Generator().manual_seed(6)
+    x = torch.rand(9, 3, 31, 17, generator=gen)
+    adv = (x + 0.05 * torch.randn(x.shape, generator=gen)).clamp(0, 1)
+    se, sn = ops().image_metrics(adv.to(DEV), x.to(DEV))
+    close(se, ((adv - x).double() ** 2).sum(dim=[1, 2, 3]), 1e-4)
+    close(sn, (x.double() ** 2).sum(dim=[1, 2, 3]), 1e-3)
+
+
+def test_errors_are_loud():
+    o = ops()
+    with pytest.raises(RuntimeError):
+        o.l1ball_project_(torch.zeros(4, 4), 0.1)                      # CPU tensor: no fallback
+    with pytest.raises(Exception):
+        o.l1ball_project_(torch.zeros(4, 300, device=DEV), 0.1)        # K > max atoms -> ADIL_EINVAL
+    with pytest.raises(TypeError):
+        o.synth(torch.zeros(2, 3, 4, 4, device=DEV, dtype=torch.float16), torch.zeros(3, 4, 4, 2, device=DEV),
+                torch.zeros(32, 16, device=DEV), 2)
