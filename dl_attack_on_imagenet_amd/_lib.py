@@ -48,6 +48,11 @@ def load(path: str = None) -> ctypes.CDLL:
     if _lib is not None and path is None:
         return _lib
     p = path or LIBPATH
+    # PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7, same as /opt/rocm's).  Importing torch
+    # first makes the dynamic loader bind our NEEDED libamdhip64.so.7 to the runtime torch already loaded, so
+    # streams and device pointers handed over by torch belong to the SAME HIP runtime instance.  Loaded the other
+    # way round the process ends up with two runtimes and every launch fails with hipErrorNoDevice.
+    import torch  # noqa: F401
     if not os.path.exists(p):
         raise AdilLibraryError(
             f"HIP kernel library not found at {p}. Build it with `python -m dl_attack_on_imagenet_amd.build` "

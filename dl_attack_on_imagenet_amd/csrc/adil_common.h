@@ -51,6 +51,10 @@ __device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// hipGetLastError is sticky per thread: drop whatever an earlier, unrelated HIP call (e.g. PyTorch's lazy device
+// probing) left behind so that ADIL_CHECK_LAUNCH reports only our own launch failures.
+#define ADIL_ENTER() (void)hipGetLastError()
+
 #define ADIL_CHECK_LAUNCH()                      \
     do {                                         \
         hipError_t e__ = hipGetLastError();      \

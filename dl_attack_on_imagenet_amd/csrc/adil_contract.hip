@@ -204,6 +204,7 @@ static int launch_synth(const void* x, const float* d, const float* vp, void* ou
 
 extern "C" int adil_synth(const void* x, const float* d, const float* vp, void* out, int B, int P, int K, int dtype,
                           float delta_clamp, int pixel_clamp, void* stream) {
+    ADIL_ENTER();
     if (!d || !vp || !out || B <= 0 || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     if (dtype == ADIL_F32) return launch_synth<float>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, (hipStream_t)stream);
     if (dtype == ADIL_BF16) return launch_synth<bf16_t>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, (hipStream_t)stream);
@@ -247,6 +248,7 @@ static int dispatch_grad(const void* g, const float* d, const float* vp, float* 
 
 extern "C" int adil_grad(const void* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P,
                          int K, int dtype, int accumulate_d, void* ws, size_t ws_bytes, void* stream) {
+    ADIL_ENTER();
     if (!g || B <= 0 || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     if (grad_d == nullptr && grad_vb == nullptr) return ADIL_EINVAL;
     if (grad_d != nullptr && !vp) return ADIL_EINVAL;

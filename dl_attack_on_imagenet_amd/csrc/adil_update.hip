@@ -350,6 +350,7 @@ extern "C" int adil_abi_version(void) { return 1; }
 extern "C" int adil_max_atoms(void) { return ADIL_MAX_ATOMS; }
 
 extern "C" int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, void* stream) {
+    ADIL_ENTER();
     if (!v || !vp || B <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     const int Kp = round_up(K, 16), Bp = round_up(B, 32);
     const int total = Bp * Kp;
@@ -362,6 +363,7 @@ extern "C" int adil_pack_codes(const float* v, const int64_t* index, int B, int 
 extern "C" int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, float* s, size_t n, float decay,
                                 float b1, float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi,
                                 float* max_abs_delta, void* stream) {
+    ADIL_ENTER();
     if (!p || !g || !m || !s || n == 0) return ADIL_EINVAL;
     if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)s | (uintptr_t)g) & 15) return ADIL_EINVAL;  // 16-B vector access
     AdamWHyper h{decay, b1, b2, eps, step_size, bc2_sqrt};
@@ -394,18 +396,21 @@ static int launch_adamw_l1ball(float* v, const float* grad_vb, const int32_t* po
 extern "C" int adil_adamw_l1ball(float* v, const float* grad_vb, const int32_t* pos, float* m, float* s, int N, int K,
                                  float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt,
                                  float radius, float* max_abs_delta, void* stream) {
+    ADIL_ENTER();
     if (!v || !grad_vb || !m || !s || N <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     AdamWHyper h{decay, b1, b2, eps, step_size, bc2_sqrt};
     return launch_adamw_l1ball(v, grad_vb, pos, m, s, N, K, h, radius, max_abs_delta, 1, (hipStream_t)stream);
 }
 
 extern "C" int adil_l1ball_project(float* x, int N, int K, float radius, void* stream) {
+    ADIL_ENTER();
     if (!x || N <= 0 || K <= 0 || K > ADIL_MAX_ATOMS || radius < 0.0f) return ADIL_EINVAL;
     AdamWHyper h{};
     return launch_adamw_l1ball(x, nullptr, nullptr, nullptr, nullptr, N, K, h, radius, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int adil_l2ball_project(float* x, int N, int K, float radius, void* stream) {
+    ADIL_ENTER();
     if (!x || N <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     const dim3 grid((N + 3) / 4), block(256);
     if (K <= 64) hipLaunchKernelGGL(l2ball_kernel<1>, grid, block, 0, (hipStream_t)stream, x, N, K, radius);
@@ -415,6 +420,7 @@ extern "C" int adil_l2ball_project(float* x, int N, int K, float radius, void* s
 }
 
 extern "C" int adil_ista_step(float* v, const float* g, size_t n, float step, float lam, void* stream) {
+    ADIL_ENTER();
     if (!v || n == 0) return ADIL_EINVAL;
     hipLaunchKernelGGL(ista_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, v, g, n, step, lam);
     ADIL_CHECK_LAUNCH();
@@ -425,6 +431,7 @@ static const int kAtomBlocks = 512;
 extern "C" size_t adil_atom_workspace_bytes(int P, int K) { (void)P; return (size_t)kAtomBlocks * K * sizeof(float); }
 
 extern "C" int adil_atom_norms(const float* d, int P, int K, float* norms, void* ws, size_t ws_bytes, void* stream) {
+    ADIL_ENTER();
     if (!d || !norms || !ws || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     if (ws_bytes < adil_atom_workspace_bytes(P, K)) return ADIL_EWORKSPACE;
     const int rows_per_block = (P + kAtomBlocks - 1) / kAtomBlocks;
@@ -440,6 +447,7 @@ extern "C" int adil_atom_norms(const float* d, int P, int K, float* norms, void*
 }
 
 extern "C" int adil_atom_scale(float* d, int P, int K, const float* norms, int sphere, void* stream) {
+    ADIL_ENTER();
     if (!d || !norms || P <= 0 || K <= 0) return ADIL_EINVAL;
     const size_t n = (size_t)P * K;
     hipLaunchKernelGGL(atom_scale_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, d, n, K, norms,
@@ -452,6 +460,7 @@ static const int kGramBlocks = 256;
 extern "C" size_t adil_gram_workspace_bytes(int P, int K) { (void)P; return (size_t)kGramBlocks * K * K * sizeof(float); }
 
 extern "C" int adil_gram(const float* d, int P, int K, float* gram, void* ws, size_t ws_bytes, void* stream) {
+    ADIL_ENTER();
     if (!d || !gram || !ws || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     if (ws_bytes < adil_gram_workspace_bytes(P, K)) return ADIL_EWORKSPACE;
     const int rows_per_block = (P + kGramBlocks - 1) / kGramBlocks;
@@ -475,6 +484,7 @@ extern "C" int adil_gram(const float* d, int P, int K, float* gram, void* ws, si
 }
 
 extern "C" int adil_dict_rightmul(const float* d, const float* mat, int P, int K, float* out, void* stream) {
+    ADIL_ENTER();
     if (!d || !mat || !out || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     const int KT = pow2_at_least(K), R = 256 / KT;
     const size_t lds = ((size_t)K * (K + 1) + (size_t)R * K) * sizeof(float);
@@ -487,6 +497,7 @@ extern "C" int adil_dict_rightmul(const float* d, const float* mat, int P, int K
 
 extern "C" int adil_image_metrics(const void* adv, const void* x, int B, int P, int dtype, float* sq_err,
                                   float* sq_norm, void* stream) {
+    ADIL_ENTER();
     if (!adv || !x || !sq_err || !sq_norm || B <= 0 || P <= 0) return ADIL_EINVAL;
     if (dtype == ADIL_F32)
         hipLaunchKernelGGL(image_metrics_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)adv,

@@ -269,7 +269,7 @@ def dict_rightmul(d: Tensor, mat: Tensor) -> Tensor:
     """D M^T as a (C,H,W,K) tensor; with M = (DtD)^-1 this is D_dagger^T (adil.py:525)."""
     lib = _lib.load()
     _dev(d, "d", torch.float32)
-    _dev(mat, "mat", torch.float32)
+    mat = _dev(mat.contiguous(), "mat", torch.float32)           # K x K: LAPACK inverses come back column-major
     p, k = dict_shape(d)
     if mat.shape != (k, k):
         raise ValueError("mat must be K x K")
