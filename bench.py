@@ -38,6 +38,10 @@ def parse_args():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--loss", default="logits", choices=["logits", "ce"])
     p.add_argument("--channels-last", type=int, default=1)
+    p.add_argument("--fold-bn", type=int, default=1,
+                   help="fold the frozen classifier's eval-mode BatchNorms into its convolutions (same function)")
+    p.add_argument("--pad-cin", type=int, default=8,
+                   help="zero-pad the first conv's 3 input channels to this width (0 = off); see zoo.ChannelPaddedConv")
     p.add_argument("--cache-labels", type=int, default=0,
                    help="1: compute the (constant) clean pseudo-labels once instead of every step (reference quirk Q4)")
     p.add_argument("--cpu-baseline", type=int, default=1)
@@ -131,7 +135,8 @@ def main():
     P = 3 * S * S
     eps = 8 / 255
 
-    model = zoo.build_classifier(args.model, seed=0, device=dev, dtype=sdtype, channels_last=bool(args.channels_last))
+    model = zoo.build_classifier(args.model, seed=0, device=dev, dtype=sdtype, channels_last=bool(args.channels_last),
+                                 fold_bn=bool(args.fold_bn), pad_input_channels=args.pad_cin)
     gen = torch.Generator().manual_seed(1000 + rank)                 # each rank owns different images (weak scaling)
     x = torch.rand(B, *shape, generator=gen).to(dev).to(sdtype).contiguous()
     gd0 = torch.Generator().manual_seed(7)                           # the same D0 on every rank
@@ -191,6 +196,8 @@ def main():
         "config": {"workload": f"ADiL learn_dictionary_a step vs {args.model}, {B} images/GPU, {K} atoms, "
                                f"{S}x{S}, {args.dtype} image streams + fp32 D/V master, loss={args.loss}, "
                                f"{'cached' if args.cache_labels else 'recomputed'} pseudo-labels (2 fwd + 1 bwd)",
+                   "classifier": f"random-init {args.model}, frozen, eval; channels_last={args.channels_last}, "
+                                 f"bn_folded={args.fold_bn}, first_conv_cin_padded_to={args.pad_cin}",
                    "global_batch": world * B, "atoms": K, "inner_iters": args.steps,
                    "parallelism": f"dp{world}: images+codes sharded, D replicated, 1 all-reduce(grad_d)/step",
                    "train_fooling_rate_last_step": fool_rate},

@@ -301,15 +301,90 @@ def canonical_name(name: str) -> str:
     return key
 
 
+# ----------------------------------------------------------------------------- frozen-classifier rewrites
+def fold_batchnorm_(module: nn.Module) -> nn.Module:
+    """Fold every eval-mode BatchNorm2d that directly follows a Conv2d into that convolution (exact in real
+    arithmetic: w' = w * gamma/sqrt(var+eps), b' = beta + (b - mean) * gamma/sqrt(var+eps)) and replace the BN by
+    Identity.  Valid for the networks of this file, whose forward applies a conv and the BatchNorm registered right
+    after it back to back.  The classifier is frozen, so this removes one elementwise pass over every activation
+    in the forward AND in the input-gradient backward (measured on MI355X, ResNet-50 B=512 bf16: 116 -> 66 ms)."""
+    for child in module.children():
+        fold_batchnorm_(child)
+    names = list(module._modules.keys())
+    for a, b in zip(names, names[1:]):
+        conv, bn = module._modules[a], module._modules[b]
+        if not (isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d)) or bn.training:
+            continue
+        with torch.no_grad():
+            scale = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+            bias = bn.bias.double() - bn.running_mean.double() * scale
+            if conv.bias is not None:
+                bias = bias + conv.bias.double() * scale
+            fused = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
+                              conv.dilation, conv.groups, bias=True, padding_mode=conv.padding_mode)
+            fused.weight.copy_((conv.weight.double() * scale.view(-1, 1, 1, 1)).float())
+            fused.bias.copy_(bias.float())
+        fused = fused.to(device=conv.weight.device, dtype=conv.weight.dtype)
+        for p in fused.parameters():
+            p.requires_grad_(False)
+        module._modules[a] = fused.eval()
+        module._modules[b] = nn.Identity()
+    return module
+
+
+class ChannelPaddedConv(nn.Module):
+    """First convolution with its 3 input channels zero-padded to `width`: MIOpen's backward-data kernels for a
+    3-channel input are pathologically slow (measured: 7x7/2 conv1 of ResNet-50, B=512 bf16 NHWC, input gradient
+    22.2 ms at C_in=3 vs 4.7 ms at C_in=8).  The extra channels carry zero weights and zero inputs."""
+
+    def __init__(self, conv: nn.Conv2d, width: int = 8):
+        super().__init__()
+        self.in_channels, self.width = conv.in_channels, width
+        wide = nn.Conv2d(width, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, conv.dilation,
+                         conv.groups, bias=conv.bias is not None)
+        with torch.no_grad():
+            wide.weight.zero_()
+            wide.weight[:, :conv.in_channels].copy_(conv.weight)
+            if conv.bias is not None:
+                wide.bias.copy_(conv.bias)
+        self.conv = wide.to(device=conv.weight.device, dtype=conv.weight.dtype)
+        for p in self.conv.parameters():
+            p.requires_grad_(False)
+
+    def forward(self, x):
+        fmt = torch.channels_last if self.conv.weight.is_contiguous(memory_format=torch.channels_last) \
+            and not self.conv.weight.is_contiguous() else torch.contiguous_format
+        xp = torch.empty((x.shape[0], self.width, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device,
+                         memory_format=fmt)
+        xp[:, self.in_channels:].zero_()
+        xp[:, :self.in_channels] = x
+        return self.conv(xp)
+
+
+def pad_first_conv_(net: nn.Module, width: int = 8) -> nn.Module:
+    """Wrap the network's first 3-channel Conv2d (groups == 1) in a ChannelPaddedConv."""
+    for parent in net.modules():
+        for name, child in parent._modules.items():
+            if isinstance(child, nn.Conv2d) and child.in_channels == 3 and child.groups == 1:
+                parent._modules[name] = ChannelPaddedConv(child, width)
+                return net
+    return net
+
+
 def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights: Optional[str] = None,
-                     device=None, dtype: torch.dtype = torch.float32, channels_last: bool = False) -> nn.Module:
-    """Sequential(Normalize, net), eval mode, parameters frozen — the object both CLIs hand to ADIL."""
+                     device=None, dtype: torch.dtype = torch.float32, channels_last: bool = False,
+                     fold_bn: bool = False, pad_input_channels: int = 0) -> nn.Module:
+    """Sequential(Normalize, net), eval mode, parameters frozen — the object both CLIs hand to ADIL.
+    fold_bn / pad_input_channels apply the function-preserving rewrites above (off by default)."""
     key = canonical_name(name)
     with torch.random.fork_rng(devices=[]):
         torch.manual_seed(seed)
         net = _BUILDERS[key](num_classes)
     if weights is not None:
         net.load_state_dict(torch.load(weights, map_location='cpu'))
+    net.eval()
+    if fold_bn:
+        fold_batchnorm_(net)
     model = nn.Sequential(Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225]), net)
     model.eval()
     for p in model.parameters():
@@ -317,4 +392,6 @@ def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights:
     model = model.to(device=device, dtype=dtype)
     if channels_last:
         model = model.to(memory_format=torch.channels_last)
+    if pad_input_channels:
+        pad_first_conv_(net, pad_input_channels)
     return model
