@@ -155,8 +155,8 @@ def grad(g: Tensor, d: Tensor, vp: Optional[Tensor], batch: int, *, want_d: bool
         grad_d = None
     if want_v:
         gvb = torch.empty(batch, k, dtype=torch.float32, device=d.device)
-        ws_bytes = lib.adil_grad_workspace_bytes(batch, p, k)
-        ws = _workspace(d.device, ws_bytes)
+    ws_bytes = lib.adil_grad_workspace_bytes(batch, p, k)
+    ws = _workspace(d.device, ws_bytes)
     _lib.check(lib.adil_grad(_ptr(g), _ptr(d), _ptr(vp), _ptr(grad_d), _ptr(gvb), batch, p, k,
                              stream_dtype_code(g.dtype), int(bool(accumulate_d)), _ptr(ws), ws_bytes, _stream()),
                "adil_grad")

@@ -143,17 +143,18 @@ def test_grad_random_f32(shape):
     # want_d / want_v individually, and accumulation into grad_d
     gd2, none = ops().grad(g.to(DEV), d.to(DEV), vp, b, want_v=False)
     assert none is None
-    close(gd2, gd, 0)
+    close(gd2, gd, 0)                                  # grad_d is accumulated in registers: bitwise reproducible
     acc = gd.clone()
     ops().grad(g.to(DEV), d.to(DEV), vp, b, want_v=False, grad_d=acc, accumulate_d=True)
     close(acc, 2 * gd, 1e-6)
     none, gv2 = ops().grad(g.to(DEV), d.to(DEV), None, b, want_d=False)
-    close(gv2, gvb, 0)
+    close(gv2, gvb, 3e-6 * p ** 0.5 * 4)               # grad_v partials meet in LDS float atomics: order-dependent last bits
 
 
 @pytest.mark.parametrize("shape", [(33, 3, 16, 16, 10), (64, 3, 20, 12, 50), (40, 3, 8, 8, 100)])
 def test_synth_grad_bf16_streams(shape):
-    """bf16 image streams, fp32 D / V / accumulation: compare with the fp32 oracle on bf16-rounded inputs."""
+    """bf16 image streams: x / g arrive in bf16, D and V are rounded to bf16 as MFMA operands, accumulation is
+    fp32.  Compared with the fp64 oracle evaluated on the bf16-rounded operands."""
     b, c, h, w, k = shape
     gen = torch.Generator().manual_seed(sum(shape) + 2)
     d = -1 + 2 * torch.rand(c, h, w, k, generator=gen)
@@ -163,12 +164,17 @@ def test_synth_grad_bf16_streams(shape):
     vp = ops().pack_codes(v.to(DEV), None, b)
     out = ops().synth(x.to(DEV), d.to(DEV), vp, b)
     assert out.dtype == torch.bfloat16
-    ref = _oracle_synth(x.float(), d, v)
+    dq, vq = d.bfloat16().float(), v.bfloat16().float()
+    ref = _oracle_synth(x.float(), dq, vq)
     close(out.float(), ref.bfloat16().float(), 2 ** -7)     # one bf16 ulp at magnitude <= 2
     gd, gvb = ops().grad(g.to(DEV), d.to(DEV), vp, b)
-    rd, rv = O.grad_dv(g.double(), d.double(), v.double())
+    rd, rv = O.grad_dv(g.double(), dq.double(), vq.double())
     close(gd, rd, 1e-5 * b ** 0.5 * 4)
     close(gvb, rv, 1e-5 * (c * h * w) ** 0.5 * 4)
+    # and the bf16 operand rounding itself stays within bf16 resolution of the fp32 result
+    rd32, rv32 = O.grad_dv(g.double(), d.double(), v.double())
+    close(gd, rd32, 2 ** -7 * 0.02 * b ** 0.5 * 4)
+    close(gvb, rv32, 2 ** -7 * (c * h * w) ** 0.5 * 4)
 
 
 def test_linearity_full_size():
