@@ -7,7 +7,7 @@ import os
 from ctypes import c_float, c_int, c_size_t, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(_PKG, "lib", "libadil_hip.so")
+LIBPATH = os.environ.get("ADIL_HIP_LIBRARY") or os.path.join(_PKG, "lib", "libadil_hip.so")
 
 # name -> (restype, argtypes); mirrors include/adil_hip.h one to one
 SIGNATURES = {

@@ -15,6 +15,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native 16-byte register quad (HIP's uint4 struct resists SROA)
 
 template <typename T> struct Mma;
 
@@ -97,36 +98,46 @@ template <typename T> struct PixVec<T, 1> {
     static __device__ __forceinline__ void load(const T* p, float (&o)[1]) { o[0] = Elem<T>::load(p, 0); }
 };
 
-// N pixels starting at p[0]; `nvalid` of them exist (tile tail); vec = rows are aligned for the vector form
-template <typename T, int N>
-__device__ __forceinline__ void load_px(const T* p, int nvalid, bool vec, float (&o)[N]) {
-    if (vec && nvalid >= N) {
-        PixVec<T, N>::load(p, o);
+// Branch-free stream access.  hipcc turns a per-element "load or zero" on a runtime condition into a branch around
+// every load with an s_waitcnt vmcnt(0) behind it (fully serialised loads), so every load below is UNCONDITIONAL on
+// a clamped, always-valid address and invalid lanes are zeroed with a select afterwards.  FAST (tile interior,
+// rows aligned) uses one vector access; the generic form loads element-wise.
+template <typename T, int N, bool FAST>
+__device__ __forceinline__ void load_px(const T* rowp, int px, int P, float (&o)[N]) {
+    if constexpr (FAST) {
+        PixVec<T, N>::load(rowp + px, o);
     } else {
 #pragma unroll
-        for (int i = 0; i < N; ++i) o[i] = (i < nvalid) ? Elem<T>::load(p, i) : 0.0f;
+        for (int i = 0; i < N; ++i) {
+            const int q = px + i;
+            o[i] = Elem<T>::load(rowp, q < P ? q : P - 1) * ((q < P) ? 1.0f : 0.0f);
+        }
     }
 }
-template <typename T>
-__device__ __forceinline__ void store_px4(T* p, int nvalid, bool vec, const float (&o)[4]) {
-    if (vec && nvalid >= 4) {
-        PixVec<T, 4>::store(p, o);
+template <typename T, bool FAST>
+__device__ __forceinline__ void store_px4(T* rowp, int px, int P, const float (&o)[4]) {
+    if constexpr (FAST) {
+        PixVec<T, 4>::store(rowp + px, o);
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i < nvalid) Elem<T>::store(p, i, o[i]);
+            if (px + i < P) Elem<T>::store(rowp, px + i, o[i]);
     }
 }
 // 8 consecutive pixels of one row as an MFMA fragment (the A operand of grad_v)
-template <typename T>
-__device__ __forceinline__ typename Mma<T>::Frag load_frag8(const T* p, int nvalid, bool vec) {
-    if (vec && nvalid >= 8) {
-        return Mma<T>::load8(reinterpret_cast<const typename Mma<T>::Elem*>(p));   // stream type == Elem type
-    }
-    float f[8];
+template <typename T, bool FAST>
+__device__ __forceinline__ typename Mma<T>::Frag load_frag8(const T* rowp, int px, int P) {
+    if constexpr (FAST) {
+        return Mma<T>::load8(reinterpret_cast<const typename Mma<T>::Elem*>(rowp + px));   // stream type == Elem type
+    } else {
+        float f[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = (i < nvalid) ? Elem<T>::load(p, i) : 0.0f;
-    return Mma<T>::from8(f);
+        for (int i = 0; i < 8; ++i) {
+            const int q = px + i;
+            f[i] = Elem<T>::load(rowp, q < P ? q : P - 1) * ((q < P) ? 1.0f : 0.0f);
+        }
+        return Mma<T>::from8(f);
+    }
 }
 
 // 8 consecutive fp32 values (16-B aligned, e.g. a row of the packed codes) as an MFMA fragment
@@ -149,47 +160,33 @@ __device__ __forceinline__ int c_row(int reg, int h) { return (reg & 3) + 8 * (r
 // =========================================================================================================== //
 #define SYNTH_TILE 128
 
-template <typename T, bool XACC>
-__global__ __launch_bounds__(256) void synth_mfma_kernel(const T* __restrict__ x, const float* __restrict__ d,
-                                                         const float* __restrict__ vp, T* __restrict__ out, int B,
-                                                         int P, int K, int Kp, float delta_clamp, int pixel_clamp,
-                                                         int vec) {
+template <typename T, bool XACC, bool FAST>
+__device__ __forceinline__ void synth_sweep(const T* __restrict__ x, const float* __restrict__ vp, T* __restrict__ out,
+                                            const typename Mma<T>::Elem* sd, int B, int P, int Kp, int Ks, int p0,
+                                            float delta_clamp, int pixel_clamp, int w, int c, int h) {
     using M = Mma<T>;
-    using E = typename M::Elem;
     using Frag = typename M::Frag;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    E* sd = reinterpret_cast<E*>(smem_raw);
-    const int Ks = Kp + M::PAD;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
-    const int p0 = blockIdx.x * SYNTH_TILE;
-    for (int i = tid; i < SYNTH_TILE * Kp; i += 256) {
-        const int r = i / Kp, k = i - r * Kp;
-        const int p = p0 + r;
-        const float val = (p < P && k < K) ? d[(size_t)p * K + k] : 0.0f;
-        sd[((r & 3) * 32 + (r >> 2)) * Ks + k] = M::to_elem(val);
-    }
-    __syncthreads();
     const int NG = Kp >> 4;
     const int nbb = (B + 31) >> 5;
     const int px = p0 + 4 * c;
-    const int nvalid = max(0, min(4, P - px));
-    const bool v4 = vec != 0;
     for (int bb = w; bb < nbb; bb += 4) {
         const int b0 = bb << 5;
         f32x16 acc[4];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const int row = b0 + c_row(reg, h);
             float xv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (XACC && row < B && nvalid > 0) load_px<T, 4>(x + (size_t)row * P + px, nvalid, v4, xv);
+            if (XACC) {
+                const int row = b0 + c_row(reg, h);
+                load_px<T, 4, FAST>(x + (size_t)(row < B ? row : B - 1) * P, px, P, xv);   // rows >= B are never stored
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t][reg] = xv[t];
         }
         const float* arow = vp + (size_t)(b0 + c) * Kp + 8 * h;
         Frag a = frag_from_f32x8<T>(arow);
         for (int g = 0; g < NG; ++g) {
-            Frag an = a;
-            if (g + 1 < NG) an = frag_from_f32x8<T>(arow + 16 * (g + 1));      // prefetch the next k-group's codes
+            const int gn = (g + 1 < NG) ? g + 1 : g;
+            const Frag an = frag_from_f32x8<T>(arow + 16 * gn);                            // prefetch the next k-group
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const Frag bf = M::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h);
@@ -200,171 +197,275 @@ __global__ __launch_bounds__(256) void synth_mfma_kernel(const T* __restrict__ x
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = b0 + c_row(reg, h);
-            if (row < B && nvalid > 0) {
-                float r[4];
+            float r[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) r[t] = acc[t][reg];
-                if (!XACC) {
-                    if (delta_clamp >= 0.0f) {
+            for (int t = 0; t < 4; ++t) r[t] = acc[t][reg];
+            if (!XACC) {
+                if (delta_clamp >= 0.0f) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) r[t] = fminf(fmaxf(r[t], -delta_clamp), delta_clamp);
-                    }
-                    if (x != nullptr) {
-                        float xv[4];
-                        load_px<T, 4>(x + (size_t)row * P + px, nvalid, v4, xv);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) r[t] += xv[t];
-                    }
+                    for (int t = 0; t < 4; ++t) r[t] = fminf(fmaxf(r[t], -delta_clamp), delta_clamp);
                 }
-                if (pixel_clamp) {
+                if (x != nullptr) {
+                    float xv[4];
+                    load_px<T, 4, FAST>(x + (size_t)(row < B ? row : B - 1) * P, px, P, xv);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) r[t] = fminf(fmaxf(r[t], 0.0f), 1.0f);
+                    for (int t = 0; t < 4; ++t) r[t] += xv[t];
                 }
-                store_px4<T>(out + (size_t)row * P + px, nvalid, v4, r);
+            }
+            if (pixel_clamp) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) r[t] = fminf(fmaxf(r[t], 0.0f), 1.0f);
+            }
+            if (row < B) store_px4<T, FAST>(out + (size_t)row * P, px, P, r);
+        }
+    }
+}
+
+template <typename T, bool XACC, bool FAST>
+__global__ __launch_bounds__(256) void synth_mfma_kernel(const T* __restrict__ x, const float* __restrict__ d,
+                                                         const float* __restrict__ vp, T* __restrict__ out, int B,
+                                                         int P, int K, int Kp, float delta_clamp, int pixel_clamp,
+                                                         int tile0) {
+    using M = Mma<T>;
+    using E = typename M::Elem;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    E* sd = reinterpret_cast<E*>(smem_raw);
+    const int Ks = Kp + M::PAD;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    const int p0 = (tile0 + blockIdx.x) * SYNTH_TILE;
+    for (int i = tid; i < SYNTH_TILE * Kp; i += 256) {
+        const int r = i / Kp, k = i - r * Kp;
+        const int p = p0 + r;
+        const float ok = ((p < P) && (k < K)) ? 1.0f : 0.0f;
+        const float val = d[(size_t)(p < P ? p : P - 1) * K + (k < K ? k : K - 1)] * ok;
+        sd[((r & 3) * 32 + (r >> 2)) * Ks + k] = M::to_elem(val);
+    }
+    __syncthreads();
+    synth_sweep<T, XACC, FAST>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp, w, c, h);
+}
+
+// =========================================================================================================== //
+// K3  grad_d = g^T vp.  Each WAVE owns pixel tiles of PXT*32 pixels and sweeps all batch rows; the grad_d tile
+// (PXT*32 px x AT*32 atoms) lives in the accumulators for the whole sweep.  A = g^T read in the coalesced
+// "lane = PXT consecutive pixels, 8 batch rows per lane" layout (PXT*64 contiguous bytes per row and half-wave),
+// B = codes from the transposed packed matrix vpt[atom][row] (L2 resident).  Waves are independent (no LDS).
+// Rows >= B are read from a clamped (valid) row and multiply zero codes.
+// =========================================================================================================== //
+template <typename T, int PXT, int AT, bool FAST>
+__global__ __launch_bounds__(256) void grad_d_mfma_kernel(const T* __restrict__ g,
+                                                          const typename Mma<T>::Elem* __restrict__ vpt, int vstride,
+                                                          float* __restrict__ grad_d, int B, int Bp, int P, int K,
+                                                          int accumulate_d, int tile_begin, int tile_end) {
+    using M = Mma<T>;
+    using Frag = typename M::Frag;
+    constexpr int TW = PXT * 32;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    const int tile = tile_begin + blockIdx.x * 4 + w;
+    if (tile >= tile_end) return;                              // whole wave exits (no barriers in this kernel)
+    const int p0 = tile * TW;
+    const int px2 = p0 + PXT * c;
+    f32x16 accd[PXT][AT];
+#pragma unroll
+    for (int t = 0; t < PXT; ++t)
+#pragma unroll
+        for (int at = 0; at < AT; ++at)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accd[t][at][r] = 0.0f;
+    // 32 batch rows (two k-groups) per iteration: all 16 row loads are issued before the first MFMA needs them
+    for (int b0 = 0; b0 < Bp; b0 += 32) {
+        float raw[2][8][PXT];
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = b0 + 16 * g2 + 8 * h + j;
+                load_px<T, PXT, FAST>(g + (size_t)(row < B ? row : B - 1) * P, px2, P, raw[g2][j]);
+            }
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+            Frag afr[PXT];
+#pragma unroll
+            for (int t = 0; t < PXT; ++t) {
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = raw[g2][j][t];
+                afr[t] = M::from8(f);
+            }
+#pragma unroll
+            for (int at = 0; at < AT; ++at) {
+                const Frag bfr = M::load8(vpt + (size_t)(at * 32 + c) * vstride + b0 + 16 * g2 + 8 * h);
+#pragma unroll
+                for (int t = 0; t < PXT; ++t) M::mma(accd[t][at], afr[t], bfr);
+            }
+        }
+    }
+    // epilogue: accumulator element (row i, lane c) of tile (t, at) is (pixel p0 + PXT*i + t, atom at*32 + c)
+#pragma unroll
+    for (int at = 0; at < AT; ++at) {
+        const int atom = at * 32 + c;
+        if (atom < K) {
+            if (accumulate_d) {
+#pragma unroll
+                for (int t = 0; t < PXT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pix = p0 + PXT * c_row(r, h) + t;
+                        if (FAST || pix < P) grad_d[(size_t)pix * K + atom] += accd[t][at][r];
+                    }
+            } else {
+#pragma unroll
+                for (int t = 0; t < PXT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pix = p0 + PXT * c_row(r, h) + t;
+                        if (FAST || pix < P) grad_d[(size_t)pix * K + atom] = accd[t][at][r];
+                    }
             }
         }
     }
 }
 
 // =========================================================================================================== //
-// K2 + K3 fused: one pass over g.  Workgroup = 8 waves (2 per SIMD); each WAVE owns pixel tiles of PXT*32
-// pixels and sweeps ALL batch blocks for them:
-//   grad_d tile (PXT*32 px x AT*32 atoms) lives in the wave's accumulators for the whole sweep (A = g^T read in
-//     the coalesced "lane = pixel, 8 batch rows per lane" layout, B = codes from the transposed packed matrix);
-//   grad_v partials (32 rows x AT*32 atoms per batch block) come from the same g block re-read in the
-//     "lane = batch row, 8 pixels per lane" layout (L1/L2 hits: the wave touched those lines a moment ago),
-//     B = this tile's D fragments held in registers; they are accumulated across tiles and waves in an LDS
-//     array [Bp][AT*32] with ds_add_f32 and flushed once per workgroup to a slab that a small kernel reduces.
+// K2 / K6  grad_vb = g D  (also v = z D_dagger^T).  Workgroup = NW waves, wave w owns batch block w (32 rows) and
+// keeps its 32 x AT*32 result in the accumulators while the workgroup walks a contiguous range of 64-pixel tiles:
+//   * the D tile is converted and staged TRANSPOSED in LDS ([atom][pixel], double buffered, one barrier per tile)
+//     and shared by all waves as the MFMA B operand;
+//   * each wave streams its 32 x 64 block of g with fully coalesced 16-byte loads (8 or 4 rows of 128 / 256
+//     contiguous bytes per instruction) into a wave-private LDS image and reads the A fragments (lane = batch row,
+//     8 consecutive pixels) back with one ds_read_b128 per k-group; row strides are padded to an odd number of
+//     16-byte slots, so both the writes and the reads are bank-conflict free.
+// No atomics anywhere: partial sums leave through one slab per workgroup and a small reduction kernel, so the
+// result is bitwise reproducible.  (A first version accumulated the partials with LDS float atomics:
+// ds_add_f32 measured ~300 cycles per wave-instruction on gfx950 and made the kernel 6x slower.)
 // =========================================================================================================== //
-template <typename T, int PXT, int AT, bool WD, bool WV>
-__global__ __launch_bounds__(512) void grad_mfma_kernel(const T* __restrict__ g, const float* __restrict__ d,
-                                                        const typename Mma<T>::Elem* __restrict__ vpt,
-                                                        int vstride, float* __restrict__ grad_d,
-                                                        float* __restrict__ slab, int B, int Bp, int P, int K,
-                                                        int accumulate_d, int vec, int ntiles) {
+#define GV_TW 64
+
+// D tile elements of one thread: consecutive threads -> consecutive atoms of one pixel (coalesced); the atom and
+// pixel tails are zeroed by a multiply (never a select on the loaded value)
+template <typename T, int AT, int NW, bool FAST>
+__device__ __forceinline__ void gv_load_d(const float* __restrict__ d, int tile, int P, int K, int tid,
+                                          float (&dreg)[(GV_TW * AT * 32 + NW * 64 - 1) / (NW * 64)]) {
+    constexpr int KA = AT * 32, NT = NW * 64, DPT = (GV_TW * KA + NT - 1) / NT;
+#pragma unroll
+    for (int e = 0; e < DPT; ++e) {
+        const int i = tid + e * NT;
+        const int px = i / KA, a = i - px * KA;
+        const int pix = tile * GV_TW + (px < GV_TW ? px : GV_TW - 1);
+        const float m = (a < K && px < GV_TW && (FAST || pix < P)) ? 1.0f : 0.0f;
+        dreg[e] = d[(size_t)((FAST || pix < P) ? pix : P - 1) * K + (a < K ? a : K - 1)] * m;
+    }
+}
+template <typename T, int AT, int NW>
+__device__ __forceinline__ void gv_write_d(typename Mma<T>::Elem* dst, int tid,
+                                           const float (&dreg)[(GV_TW * AT * 32 + NW * 64 - 1) / (NW * 64)]) {
     using M = Mma<T>;
+    constexpr int KA = AT * 32, NT = NW * 64, DPT = (GV_TW * KA + NT - 1) / NT, GS = GV_TW + M::PAD;
+#pragma unroll
+    for (int e = 0; e < DPT; ++e) {
+        const int i = tid + e * NT;
+        const int px = i / KA, a = i - px * KA;
+        if (px < GV_TW) dst[a * GS + px] = M::to_elem(dreg[e]);
+    }
+}
+// this wave's 32 x 64 block of g: NLD fully coalesced 16-byte loads per lane
+template <typename T, bool FAST>
+__device__ __forceinline__ void gv_load_g(const T* __restrict__ g, int tile, int b0, int B, int P, int lrow, int lcol,
+                                          u32x4 (&blk)[32 / (64 / (GV_TW / (16 / (int)sizeof(T))))]) {
+    constexpr int EPL = 16 / sizeof(T), LPR = GV_TW / EPL, RPI = 64 / LPR, NLD = 32 / RPI;
+    const int p0 = tile * GV_TW;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int row = b0 + i * RPI + lrow;
+        const T* rowp = g + (size_t)(row < B ? row : B - 1) * P;         // rows >= B: valid address, result discarded
+        if constexpr (FAST) {
+            blk[i] = *reinterpret_cast<const u32x4*>(rowp + p0 + lcol);
+        } else {                                                  // ragged tail / unaligned rows: element-wise, clamped
+            unsigned wds[4];                                      // (pixels beyond P meet zero rows of the D tile)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = p0 + lcol + e * (EPL / 4);
+                if constexpr (sizeof(T) == 4) {
+                    wds[e] = __float_as_uint(reinterpret_cast<const float*>(rowp)[q < P ? q : P - 1]);
+                } else {
+                    const unsigned lo = reinterpret_cast<const bf16_t*>(rowp)[q < P ? q : P - 1];
+                    const unsigned hi = reinterpret_cast<const bf16_t*>(rowp)[q + 1 < P ? q + 1 : P - 1];
+                    wds[e] = lo | (hi << 16);
+                }
+            }
+            blk[i] = u32x4{wds[0], wds[1], wds[2], wds[3]};
+        }
+    }
+}
+
+template <typename T, int AT, int NW, bool FAST>
+__global__ __launch_bounds__(NW * 64) void grad_v_mfma_kernel(const T* __restrict__ g, const float* __restrict__ d,
+                                                              float* __restrict__ slab, int B, int Bp, int P, int K,
+                                                              int tile_begin, int tile_end, int tiles_per_wg) {
+    using M = Mma<T>;
+    using E = typename M::Elem;
     using Frag = typename M::Frag;
     constexpr int KA = AT * 32;
-    constexpr int TW = PXT * 32;
-    constexpr int NG3 = TW / 16;
-    extern __shared__ __attribute__((aligned(16))) float sacc[];          // [Bp][KA], WV only
+    constexpr int GS = GV_TW + M::PAD;                       // row stride (elements): odd number of 16-B slots
+    constexpr int EPL = 16 / sizeof(E);                          // elements per 16-byte lane access
+    constexpr int LPR = GV_TW / EPL;                             // lanes per row of the g block
+    constexpr int RPI = 64 / LPR;                                // rows per load instruction
+    constexpr int NLD = 32 / RPI;                                // load instructions per 32-row block
+    constexpr int NT = NW * 64;
+    constexpr int DPT = (GV_TW * KA + NT - 1) / NT;              // D-tile elements per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    E* sdt = reinterpret_cast<E*>(smem_raw);                     // [2][KA][GS]  transposed D tile, double buffered
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
-    if (WV) {
-        for (int i = tid; i < Bp * KA; i += 512) sacc[i] = 0.0f;
-        __syncthreads();
-    }
-    const bool vok = vec != 0;
-    const int nbb = Bp >> 5;
-    const int nwaves = gridDim.x * 8;
-    for (int tile = blockIdx.x * 8 + w; tile < ntiles; tile += nwaves) {
-        const int p0 = tile * TW;
-        Frag dfr[NG3][AT];
-        if (WV) {
+    E* sg = sdt + 2 * KA * GS + (size_t)w * 32 * GS;             // this wave's [32][GS] image of its g block
+    const int t0 = tile_begin + blockIdx.x * tiles_per_wg;
+    const int t1 = min(tile_end, t0 + tiles_per_wg);
+    const int b0 = w << 5;
+    const bool active = b0 < Bp;                                 // waves beyond the batch only help staging D
+    f32x16 accv[AT];
 #pragma unroll
-            for (int g3 = 0; g3 < NG3; ++g3) {
+    for (int at = 0; at < AT; ++at)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accv[at][r] = 0.0f;
+    const int lrow = lane / LPR, lcol = (lane - lrow * LPR) * EPL;
+
+    float dreg[DPT];
+    u32x4 blk[NLD];
+    if (t0 < t1) {
+        gv_load_d<T, AT, NW, FAST>(d, t0, P, K, tid, dreg);
+        if (active) gv_load_g<T, FAST>(g, t0, b0, B, P, lrow, lcol, blk);
+        gv_write_d<T, AT, NW>(sdt, tid, dreg);
+    }
+    for (int tile = t0; tile < t1; ++tile) {
+        const int buf = (tile - t0) & 1;
+        const bool more = tile + 1 < t1;
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(sg + (i * RPI + lrow) * GS + lcol) = blk[i];
+        }
+        if (more) {                                               // next tile's loads fly under this tile's MFMAs
+            gv_load_d<T, AT, NW, FAST>(d, tile + 1, P, K, tid, dreg);
+            if (active) gv_load_g<T, FAST>(g, tile + 1, b0, B, P, lrow, lcol, blk);
+        }
+        __syncthreads();                                          // D[buf] complete; everyone is done reading D[buf^1]
+        if (active) {
+            const E* sdb = sdt + buf * KA * GS;
+#pragma unroll
+            for (int g3 = 0; g3 < GV_TW / 16; ++g3) {
+                const Frag a = M::load8(sg + c * GS + 16 * g3 + 8 * h);
 #pragma unroll
                 for (int at = 0; at < AT; ++at) {
-                    float f[8];
-                    const int atom = at * 32 + c;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int pix = p0 + 16 * g3 + 8 * h + j;
-                        f[j] = (pix < P && atom < K) ? d[(size_t)pix * K + atom] : 0.0f;
-                    }
-                    dfr[g3][at] = M::from8(f);
+                    const Frag bfr = M::load8(sdb + (at * 32 + c) * GS + 16 * g3 + 8 * h);
+                    M::mma(accv[at], a, bfr);
                 }
             }
         }
-        f32x16 accd[PXT][AT];
-        if (WD) {
-#pragma unroll
-            for (int t = 0; t < PXT; ++t)
-#pragma unroll
-                for (int at = 0; at < AT; ++at)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) accd[t][at][r] = 0.0f;
-        }
-        const int px2 = p0 + PXT * c;                            // layout 2: this lane's PXT pixels
-        const int nv2 = max(0, min(PXT, P - px2));
-        for (int bb = 0; bb < nbb; ++bb) {
-            const int b0 = bb << 5;
-            if (WD) {
-#pragma unroll
-                for (int g2 = 0; g2 < 2; ++g2) {
-                    float raw[8][PXT];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int row = b0 + 16 * g2 + 8 * h + j;
-#pragma unroll
-                        for (int t = 0; t < PXT; ++t) raw[j][t] = 0.0f;
-                        if (row < B && nv2 > 0) load_px<T, PXT>(g + (size_t)row * P + px2, nv2, vok, raw[j]);
-                    }
-                    Frag afr[PXT];
-#pragma unroll
-                    for (int t = 0; t < PXT; ++t) {
-                        float f[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) f[j] = raw[j][t];
-                        afr[t] = M::from8(f);
-                    }
-#pragma unroll
-                    for (int at = 0; at < AT; ++at) {
-                        const Frag bfr = M::load8(vpt + (size_t)(at * 32 + c) * vstride + b0 + 16 * g2 + 8 * h);
-#pragma unroll
-                        for (int t = 0; t < PXT; ++t) M::mma(accd[t][at], afr[t], bfr);
-                    }
-                }
-            }
-            if (WV) {
-                f32x16 accv[AT];
-#pragma unroll
-                for (int at = 0; at < AT; ++at)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) accv[at][r] = 0.0f;
-                const int row = b0 + c;
-#pragma unroll
-                for (int g3 = 0; g3 < NG3; ++g3) {
-                    const int px3 = p0 + 16 * g3 + 8 * h;
-                    const int nv3 = (row < B) ? max(0, min(8, P - px3)) : 0;
-                    Frag a3;
-                    if (nv3 > 0) {
-                        a3 = load_frag8<T>(g + (size_t)row * P + px3, nv3, vok);
-                    } else {
-                        const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                        a3 = M::from8(z);
-                    }
-#pragma unroll
-                    for (int at = 0; at < AT; ++at) M::mma(accv[at], a3, dfr[g3][at]);
-                }
-#pragma unroll
-                for (int at = 0; at < AT; ++at)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        atomicAdd(&sacc[(b0 + c_row(r, h)) * KA + at * 32 + c], accv[at][r]);
-            }
-        }
-        if (WD) {
-#pragma unroll
-            for (int t = 0; t < PXT; ++t)
-#pragma unroll
-                for (int at = 0; at < AT; ++at) {
-                    const int atom = at * 32 + c;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int pix = p0 + PXT * c_row(r, h) + t;
-                        if (pix < P && atom < K) {
-                            const size_t o = (size_t)pix * K + atom;
-                            grad_d[o] = accumulate_d ? grad_d[o] + accd[t][at][r] : accd[t][at][r];
-                        }
-                    }
-                }
-        }
+        if (more) gv_write_d<T, AT, NW>(sdt + (buf ^ 1) * KA * GS, tid, dreg);
     }
-    if (WV) {
-        __syncthreads();
-        float4* dst = reinterpret_cast<float4*>(slab + (size_t)blockIdx.x * Bp * KA);
-        const float4* src = reinterpret_cast<const float4*>(sacc);
-        for (int i = tid; i < Bp * KA / 4; i += 512) dst[i] = src[i];
+    if (active) {                                                 // partial sums of this workgroup: slab[wg][row][atom]
+        float* dst = slab + (size_t)blockIdx.x * Bp * KA;
+#pragma unroll
+        for (int at = 0; at < AT; ++at)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(size_t)(b0 + c_row(r, h)) * KA + at * 32 + c] = accv[at][r];
     }
 }
 
@@ -393,7 +494,6 @@ __global__ __launch_bounds__(256) void grad_v_reduce_kernel(const float* __restr
 // C ABI
 // =========================================================================================================== //
 static const int kNumCU = 256;                     // MI355X
-static const size_t kLdsAccumBytes = 128 * 1024;   // LDS budget of the grad_v accumulator (of 160 KiB per CU)
 
 static int set_lds(const void* fn, size_t bytes) {
     if (bytes > 48 * 1024) {
@@ -405,47 +505,50 @@ static int set_lds(const void* fn, size_t bytes) {
 
 static inline int atom_tiles(int K) { return (K + 31) / 32; }
 static inline int grad_at(int K) { const int a = atom_tiles(K); return a <= 2 ? a : 4; }       // instantiated: 1, 2, 4
-static inline int grad_pxt(int K) { return grad_at(K) <= 2 ? 2 : 1; }
-static inline int grad_chunk_rows(int B, int K) {                                              // batch rows per launch
-    const int KA = grad_at(K) * 32;
-    int rows = (int)(kLdsAccumBytes / (KA * sizeof(float))) / 32 * 32;
-    const int Bp = round_up(B, 32);
-    return rows < Bp ? rows : Bp;
-}
-static inline int grad_num_wgs(int P, int K) {
-    const int ntiles = (P + grad_pxt(K) * 32 - 1) / (grad_pxt(K) * 32);
-    int wgs = (ntiles + 7) / 8;
-    return wgs < kNumCU ? wgs : kNumCU;
-}
 
 extern "C" size_t adil_grad_workspace_bytes(int B, int P, int K) {
+    (void)P;
     const size_t KA = grad_at(K) * 32, Bp = round_up(B, 32);
-    const size_t vpt = KA * Bp * sizeof(float);
-    const size_t slab = (size_t)grad_num_wgs(P, K) * grad_chunk_rows(B, K) * KA * sizeof(float);
+    const size_t vpt = KA * Bp * sizeof(float);                       // transposed codes (grad_d)
+    const size_t rows = Bp < 512 ? Bp : 512;
+    const size_t slab = (size_t)(2 * kNumCU + 2) * rows * KA * sizeof(float);   // grad_v partial sums per workgroup
     return ((vpt + 255) / 256) * 256 + slab;
+}
+
+template <typename T, bool XACC, bool FAST>
+static int launch_synth_range(const void* x, const float* d, const float* vp, void* out, int B, int P, int K,
+                              float delta_clamp, int pixel_clamp, int tile0, int ntiles, hipStream_t st) {
+    using E = typename Mma<T>::Elem;
+    if (ntiles <= 0) return 0;
+    const int Kp = round_up(K, 16);
+    const size_t lds = (size_t)SYNTH_TILE * (Kp + Mma<T>::PAD) * sizeof(E);
+    int rc = set_lds((const void*)synth_mfma_kernel<T, XACC, FAST>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((synth_mfma_kernel<T, XACC, FAST>), dim3(ntiles), dim3(256), lds, st, (const T*)x, d, vp, (T*)out,
+                       B, P, K, Kp, delta_clamp, pixel_clamp, tile0);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+// full (interior, vector-aligned) tiles go through the FAST kernel, the ragged tail / unaligned rows through the
+// element-wise one
+template <typename T, bool XACC>
+static int launch_synth_x(const void* x, const float* d, const float* vp, void* out, int B, int P, int K,
+                          float delta_clamp, int pixel_clamp, hipStream_t st) {
+    const bool vec = (P % 4 == 0) && (((uintptr_t)out | (uintptr_t)x) % 16 == 0);
+    const int ntiles = (P + SYNTH_TILE - 1) / SYNTH_TILE;
+    const int nfast = vec ? P / SYNTH_TILE : 0;
+    int rc = launch_synth_range<T, XACC, true>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, 0, nfast, st);
+    if (rc) return rc;
+    return launch_synth_range<T, XACC, false>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, nfast, ntiles - nfast, st);
 }
 
 template <typename T>
 static int launch_synth(const void* x, const float* d, const float* vp, void* out, int B, int P, int K,
                         float delta_clamp, int pixel_clamp, hipStream_t st) {
-    using E = typename Mma<T>::Elem;
-    const int Kp = round_up(K, 16);
-    const size_t lds = (size_t)SYNTH_TILE * (Kp + Mma<T>::PAD) * sizeof(E);
-    const int vec = (P % 4 == 0) && (((uintptr_t)out | (uintptr_t)x) % 16 == 0);
     const bool xacc = (x != nullptr) && (delta_clamp < 0.0f);
-    const dim3 grid((P + SYNTH_TILE - 1) / SYNTH_TILE), block(256);
-    int rc;
-    if (xacc) {
-        if ((rc = set_lds((const void*)synth_mfma_kernel<T, true>, lds))) return rc;
-        hipLaunchKernelGGL((synth_mfma_kernel<T, true>), grid, block, lds, st, (const T*)x, d, vp, (T*)out, B, P, K, Kp,
-                           delta_clamp, pixel_clamp, vec);
-    } else {
-        if ((rc = set_lds((const void*)synth_mfma_kernel<T, false>, lds))) return rc;
-        hipLaunchKernelGGL((synth_mfma_kernel<T, false>), grid, block, lds, st, (const T*)x, d, vp, (T*)out, B, P, K, Kp,
-                           delta_clamp, pixel_clamp, vec);
-    }
-    ADIL_CHECK_LAUNCH();
-    return 0;
+    if (xacc) return launch_synth_x<T, true>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, st);
+    return launch_synth_x<T, false>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, st);
 }
 
 extern "C" int adil_synth(const void* x, const float* d, const float* vp, void* out, int B, int P, int K, int dtype,
@@ -457,58 +560,116 @@ extern "C" int adil_synth(const void* x, const float* d, const float* vp, void* 
     return ADIL_EINVAL;
 }
 
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+template <typename T, int PXT, int AT, bool FAST>
+static int launch_grad_d_range(const T* g, const typename Mma<T>::Elem* vpt, int vstride, float* grad_d, int B, int Bp,
+                               int P, int K, int acc_d, int tile_begin, int tile_end, hipStream_t st) {
+    const int n = tile_end - tile_begin;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL((grad_d_mfma_kernel<T, PXT, AT, FAST>), dim3((n + 3) / 4), dim3(256), 0, st, g, vpt, vstride, grad_d,
+                       B, Bp, P, K, acc_d, tile_begin, tile_end);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T, int PXT, int AT>
+static int launch_grad_d(const T* g, const float* vp, float* grad_d, int B, int P, int K, int accumulate_d, void* ws,
+                         hipStream_t st) {
+    using E = typename Mma<T>::Elem;
+    constexpr int KA = AT * 32;
+    constexpr int TW = PXT * 32;
+    const int Kp = round_up(K, 16), Bp = round_up(B, 32);
+    E* vpt = reinterpret_cast<E*>(ws);
+    hipLaunchKernelGGL((transpose_codes_kernel<E>), dim3((KA * Bp + 255) / 256), dim3(256), 0, st, vp, Bp, Kp, KA, vpt);
+    ADIL_CHECK_LAUNCH();
+    const int ntiles = (P + TW - 1) / TW;
+    const bool vec = (P % 4 == 0) && ((uintptr_t)g % 16 == 0);
+    const int nfast = vec ? P / TW : 0;
+    int rc = launch_grad_d_range<T, PXT, AT, true>(g, vpt, Bp, grad_d, B, Bp, P, K, accumulate_d, 0, nfast, st);
+    if (rc) return rc;
+    return launch_grad_d_range<T, PXT, AT, false>(g, vpt, Bp, grad_d, B, Bp, P, K, accumulate_d, nfast, ntiles, st);
+}
+
+// waves (= 32-row batch blocks) per grad_v workgroup: bounded by the 160 KiB of LDS holding one g image per wave
+template <typename T> struct GradVWaves { static constexpr int kMax = sizeof(T) == 2 ? 16 : 8; };
+
+template <typename T, int AT>
+static size_t grad_v_lds_bytes(int nwaves) {
+    using E = typename Mma<T>::Elem;
+    const size_t GS = GV_TW + Mma<T>::PAD;
+    return (2 * (size_t)AT * 32 * GS + (size_t)nwaves * 32 * GS) * sizeof(E);
+}
+
+template <typename T, int AT, int NW, bool FAST>
+static int launch_grad_v_nw(const T* g, const float* d, float* slab, int rows, int rows_p, int P, int K, int tile_begin,
+                            int tile_end, int nwg, int tiles_per_wg, hipStream_t st) {
+    const size_t lds = grad_v_lds_bytes<T, AT>(NW);
+    int rc = set_lds((const void*)grad_v_mfma_kernel<T, AT, NW, FAST>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((grad_v_mfma_kernel<T, AT, NW, FAST>), dim3(nwg), dim3(NW * 64), lds, st, g, d, slab, rows, rows_p, P,
+                       K, tile_begin, tile_end, tiles_per_wg);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T, int AT, bool FAST>
+static int launch_grad_v_range(const T* g, const float* d, float* slab, int rows, int rows_p, int P, int K, int tile_begin,
+                               int tile_end, int nwg, int tiles_per_wg, hipStream_t st) {
+    if (nwg <= 0) return 0;
+    const int nwaves = rows_p / 32;                               // <= GradVWaves<T>::kMax
+    if constexpr (GradVWaves<T>::kMax >= 16) {
+        if (nwaves > 8) return launch_grad_v_nw<T, AT, 16, FAST>(g, d, slab, rows, rows_p, P, K, tile_begin, tile_end, nwg, tiles_per_wg, st);
+    }
+    if (nwaves > 4) return launch_grad_v_nw<T, AT, 8, FAST>(g, d, slab, rows, rows_p, P, K, tile_begin, tile_end, nwg, tiles_per_wg, st);
+    return launch_grad_v_nw<T, AT, 4, FAST>(g, d, slab, rows, rows_p, P, K, tile_begin, tile_end, nwg, tiles_per_wg, st);
+}
+
+template <typename T, int AT>
+static int launch_grad_v(const T* g, const float* d, float* grad_vb, int B, int P, int K, float* slab, hipStream_t st) {
+    constexpr int KA = AT * 32;
+    const int Bp = round_up(B, 32);
+    const int ntiles = (P + GV_TW - 1) / GV_TW;
+    const bool vec = (P % 8 == 0) && ((uintptr_t)g % 16 == 0);
+    const int nfast = vec ? P / GV_TW : 0, nslow = ntiles - nfast;
+    const int tpw_fast = nfast > 0 ? (nfast + kNumCU - 1) / kNumCU : 1;
+    const int nwg_fast = nfast > 0 ? (nfast + tpw_fast - 1) / tpw_fast : 0;
+    const int tpw_slow = nslow > 0 ? (nslow + kNumCU - 1) / kNumCU : 1;
+    const int nwg_slow = nslow > 0 ? (nslow + tpw_slow - 1) / tpw_slow : 0;
+    const int chunk = GradVWaves<T>::kMax * 32;
+    for (int r0 = 0; r0 < Bp; r0 += chunk) {
+        const int rows_p = imin(Bp - r0, chunk), rows = imin(B - r0, rows_p);
+        const T* gc = g + (size_t)r0 * P;
+        int rc = launch_grad_v_range<T, AT, true>(gc, d, slab, rows, rows_p, P, K, 0, nfast, nwg_fast, tpw_fast, st);
+        if (rc) return rc;
+        rc = launch_grad_v_range<T, AT, false>(gc, d, slab + (size_t)nwg_fast * rows_p * KA, rows, rows_p, P, K, nfast,
+                                               ntiles, nwg_slow, tpw_slow, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows * K + 255) / 256), dim3(256), 0, st, (const float*)slab,
+                           nwg_fast + nwg_slow, rows_p, KA, rows, K, grad_vb + (size_t)r0 * K);
+        ADIL_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 template <typename T, int PXT, int AT>
 static int launch_grad_cfg(const T* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P,
                            int K, int accumulate_d, void* ws, hipStream_t st) {
-    using E = typename Mma<T>::Elem;
     constexpr int KA = AT * 32;
-    const int Kp = round_up(K, 16), Bp = round_up(B, 32);
-    const int ntiles = (P + PXT * 32 - 1) / (PXT * 32);
-    const int nwg = grad_num_wgs(P, K);
-    E* vpt = reinterpret_cast<E*>(ws);
+    const int Bp = round_up(B, 32);
     float* slab = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + (((size_t)KA * Bp * sizeof(float) + 255) / 256) * 256);
-    const int vec = (P % 8 == 0) && ((uintptr_t)g % 16 == 0);
-    if (grad_d != nullptr) {
-        hipLaunchKernelGGL((transpose_codes_kernel<E>), dim3((KA * Bp + 255) / 256), dim3(256), 0, st, vp, Bp, Kp, KA, vpt);
-        ADIL_CHECK_LAUNCH();
-    }
-    const int chunk = grad_chunk_rows(B, K);
-    for (int r0 = 0; r0 < Bp; r0 += chunk) {
-        const int rows_p = (Bp - r0 < chunk) ? (Bp - r0) : chunk;           // padded rows in this chunk
-        const int rows = (B - r0 < rows_p) ? (B - r0) : rows_p;             // real rows
-        const T* gc = g + (size_t)r0 * P;
-        const int acc_d = accumulate_d || (r0 > 0);
-        int rc;
-        // NOTE: vpt is indexed [atom][Bp] with the chunk's column offset r0 folded into the pointer
-        if (grad_d != nullptr && grad_vb != nullptr) {
-            const size_t lds = (size_t)rows_p * KA * sizeof(float);
-            if ((rc = set_lds((const void*)grad_mfma_kernel<T, PXT, AT, true, true>, lds))) return rc;
-            hipLaunchKernelGGL((grad_mfma_kernel<T, PXT, AT, true, true>), dim3(nwg), dim3(512), lds, st, gc, d, vpt + r0,
-                               Bp, grad_d, slab, rows, rows_p, P, K, acc_d, vec, ntiles);
-        } else if (grad_d != nullptr) {
-            hipLaunchKernelGGL((grad_mfma_kernel<T, PXT, AT, true, false>), dim3(nwg), dim3(512), 0, st, gc, d, vpt + r0,
-                               Bp, grad_d, slab, rows, rows_p, P, K, acc_d, vec, ntiles);
-        } else {
-            const size_t lds = (size_t)rows_p * KA * sizeof(float);
-            if ((rc = set_lds((const void*)grad_mfma_kernel<T, PXT, AT, false, true>, lds))) return rc;
-            hipLaunchKernelGGL((grad_mfma_kernel<T, PXT, AT, false, true>), dim3(nwg), dim3(512), lds, st, gc, d, vpt + r0,
-                               Bp, grad_d, slab, rows, rows_p, P, K, acc_d, vec, ntiles);
-        }
-        ADIL_CHECK_LAUNCH();
-        if (grad_vb != nullptr) {
-            hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows * K + 255) / 256), dim3(256), 0, st, (const float*)slab, nwg,
-                               rows_p, KA, rows, K, grad_vb + (size_t)r0 * K);
-            ADIL_CHECK_LAUNCH();
-        }
-    }
-    return 0;
+    int rc = 0;
+    if (grad_d != nullptr) rc = launch_grad_d<T, PXT, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, st);
+    if (rc) return rc;
+    if (grad_vb != nullptr) rc = launch_grad_v<T, AT>(g, d, grad_vb, B, P, K, slab, st);
+    return rc;
 }
 
 template <typename T>
 static int launch_grad(const void* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P,
                        int K, int accumulate_d, void* ws, hipStream_t st) {
     const int at = grad_at(K);
-    if (at == 1) return launch_grad_cfg<T, 2, 1>((const T*)g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, st);
+    if (at == 1) return launch_grad_cfg<T, 4, 1>((const T*)g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, st);
     if (at == 2) return launch_grad_cfg<T, 2, 2>((const T*)g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, st);
     return launch_grad_cfg<T, 1, 4>((const T*)g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, st);
 }

@@ -1,0 +1,40 @@
+"""GPU micro-benchmark of the hand-written kernels at the BASELINE shape (not part of the product)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dl_attack_on_imagenet_amd import ops
+
+dev = torch.device("cuda")
+B = int(os.environ.get("B", 512)); K = int(os.environ.get("K", 50)); S = int(os.environ.get("S", 224))
+P = 3 * S * S
+only = os.environ.get("ONLY", "")
+
+def timeit(fn, n=20, w=3):
+    for _ in range(w): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+g0 = torch.Generator().manual_seed(0)
+d = (-1 + 2 * torch.rand(3, S, S, K, generator=g0)).to(dev)
+v = (torch.randn(B, K, generator=g0) * 0.01).to(dev)
+vp = ops.pack_codes(v, None, B)
+for dt, s in ((torch.bfloat16, 2), (torch.float32, 4)):
+    x = torch.rand(B, 3, S, S, generator=g0).to(dev).to(dt)
+    g = torch.randn(B, 3, S, S, generator=g0).to(dev).to(dt)
+    out = torch.empty_like(x); gd = torch.empty_like(d)
+    rows = []
+    t = timeit(lambda: ops.synth(x, d, vp, B, out=out)); rows.append(("synth", t, 2 * B * P * s + P * K * 4))
+    t = timeit(lambda: ops.grad(g, d, vp, B, grad_d=gd)); rows.append(("grad d+v", t, B * P * s + 2 * P * K * 4))
+    t = timeit(lambda: ops.grad(g, d, vp, B, want_v=False, grad_d=gd)); rows.append(("grad d only", t, B * P * s + P * K * 4))
+    t = timeit(lambda: ops.grad(g, d, None, B, want_d=False)); rows.append(("grad v only", t, B * P * s + P * K * 4))
+    t = timeit(lambda: out.copy_(x)); rows.append(("torch copy (ref)", t, 2 * B * P * s))
+    for name, t, byt in rows:
+        print(f"{str(dt):16s} {name:18s} {t*1e3:9.1f} us   {byt/t/1e6:8.1f} GB/s algorithmic", flush=True)
+m, sq = torch.zeros_like(d), torch.zeros_like(d)
+h = ops.AdamWSchedule(0.01).next()
+gd = torch.randn_like(d)
+t = timeit(lambda: ops.adamw_clamp_(d, gd, m, sq, h, -1.0, 1.0)); print(f"adamw_clamp(D)  {t*1e3:9.1f} us  {7*P*K*4/t/1e6:8.1f} GB/s")
