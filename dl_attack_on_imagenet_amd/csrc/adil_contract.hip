@@ -480,14 +480,32 @@ __global__ __launch_bounds__(256) void transpose_codes_kernel(const float* __res
     if constexpr (sizeof(E) == 4) vpt[i] = v; else vpt[i] = f32_to_bf16(v);
 }
 
+// grad_vb[b][k] = sum over workgroup slabs.  64 consecutive (b, k) entries per block x 4 slab groups; every thread
+// keeps 8 independent loads in flight, the 4 groups meet in LDS in a fixed order (bitwise reproducible).
 __global__ __launch_bounds__(256) void grad_v_reduce_kernel(const float* __restrict__ slab, int nslabs, int Bp, int KA,
                                                             int B, int K, float* __restrict__ grad_vb) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * K) return;
-    const int b = i / K, k = i - b * K;
-    float acc = 0.0f;
-    for (int s = 0; s < nslabs; ++s) acc += slab[((size_t)s * Bp + b) * KA + k];
-    grad_vb[i] = acc;
+    __shared__ float part[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);          // entry of the padded [Bp][KA] matrix
+    const int grp = threadIdx.x >> 6;
+    const size_t stride = (size_t)Bp * KA;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.0f;
+    if (e < Bp * KA) {
+        int sidx = grp;
+        for (; sidx + 28 < nslabs; sidx += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += slab[(size_t)(sidx + 4 * u) * stride + e];
+        }
+        for (; sidx < nslabs; sidx += 4) acc[0] += slab[(size_t)sidx * stride + e];
+    }
+    part[grp][threadIdx.x & 63] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (grp == 0 && e < Bp * KA) {
+        const int b = e / KA, k = e - b * KA;
+        if (b < B && k < K)
+            grad_vb[(size_t)b * K + k] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    }
 }
 
 // =========================================================================================================== //
@@ -645,7 +663,7 @@ static int launch_grad_v(const T* g, const float* d, float* grad_vb, int B, int 
         rc = launch_grad_v_range<T, AT, false>(gc, d, slab + (size_t)nwg_fast * rows_p * KA, rows, rows_p, P, K, nfast,
                                                ntiles, nwg_slow, tpw_slow, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows * K + 255) / 256), dim3(256), 0, st, (const float*)slab,
+        hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows_p * KA + 63) / 64), dim3(256), 0, st, (const float*)slab,
                            nwg_fast + nwg_slow, rows_p, KA, rows, K, grad_vb + (size_t)r0 * K);
         ADIL_CHECK_LAUNCH();
     }
