@@ -142,7 +142,9 @@ def main():
     gd0 = torch.Generator().manual_seed(7)                           # the same D0 on every rank
     d = (-1 + 2 * torch.rand(*shape, K, generator=gd0)).to(dev)
     v = ops.l1ball_project_(torch.rand(B, K, generator=gen).to(dev), eps)
-    reducer = adist.DictGradReducer() if world > 1 else None
+    # ADIL_FORCE_REDUCER=1 exercises the RCCL path (process group, all-reduce of grad_d) even with one rank
+    force = os.environ.get("ADIL_FORCE_REDUCER") == "1" and torch.distributed.is_initialized()
+    reducer = adist.DictGradReducer() if (world > 1 or force) else None
     learner = engine.DictionaryLearner(d, v, eps, 0.01, args.loss, False, 50.0, reducer=reducer)
     index = torch.arange(B, device=dev)
     labels = engine.predict(model, x) if args.cache_labels else None

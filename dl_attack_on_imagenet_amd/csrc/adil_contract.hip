@@ -233,12 +233,24 @@ __global__ __launch_bounds__(256) void synth_mfma_kernel(const T* __restrict__ x
     const int Ks = Kp + M::PAD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int p0 = (tile0 + blockIdx.x) * SYNTH_TILE;
-    for (int i = tid; i < SYNTH_TILE * Kp; i += 256) {
-        const int r = i / Kp, k = i - r * Kp;
-        const int p = p0 + r;
-        const float ok = ((p < P) && (k < K)) ? 1.0f : 0.0f;
-        const float val = d[(size_t)(p < P ? p : P - 1) * K + (k < K ? k : K - 1)] * ok;
-        sd[((r & 3) * 32 + (r >> 2)) * Ks + k] = M::to_elem(val);
+    // D slice -> LDS.  SYNTH_TILE*Kp/256 = Kp/2 elements per thread, a multiple of 8: eight independent loads are
+    // issued before the first conversion (a rolled loop would pay one full memory latency per element)
+    for (int i0 = tid; i0 < SYNTH_TILE * Kp; i0 += 256 * 8) {
+        float val[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 256 * u;
+            const int r = i / Kp, k = i - r * Kp;
+            const int p = p0 + r;
+            const float ok = ((p < P) && (k < K)) ? 1.0f : 0.0f;
+            val[u] = d[(size_t)(p < P ? p : P - 1) * K + (k < K ? k : K - 1)] * ok;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 256 * u;
+            const int r = i / Kp, k = i - r * Kp;
+            sd[((r & 3) * 32 + (r >> 2)) * Ks + k] = M::to_elem(val[u]);
+        }
     }
     __syncthreads();
     synth_sweep<T, XACC, FAST>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp, w, c, h);

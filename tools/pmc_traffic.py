@@ -32,6 +32,8 @@ def short(name):
                   r"adamw_l1ball_kernel|pack_codes_kernel|transpose_codes_kernel)<([^>]*)", name)
     if m:
         return f"{m.group(1)}<{m.group(2).split('>')[0]}>"
+    if "grad_v_reduce_kernel" in name:
+        return "grad_v_reduce_kernel"
     if "direct_copy_kernel" in name or "copy" in name.lower():
         return "torch_copy"
     return None
