@@ -214,7 +214,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, shape)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
