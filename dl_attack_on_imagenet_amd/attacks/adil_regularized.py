@@ -242,6 +242,122 @@ def sadil(dataset, model, targeted=True, nepochs=1e3, batchsize=1, lambdaCoding=
     return D, v, None
 
 
+def sadil_updated(dataset, model, targeted=True, nepochs=1e3, batchsize=1, lambdaCoding=1., l2_fool=1., stepsize=1.,
+                  n_atom=5, dict_set='l2ball', device="cuda", model_file=None, init_dictionary=None):
+    """Large-scale variant: per-batch ISTA step on the codes with a backtracking probe, one dictionary step per epoch
+    with a line search (delta = beta = .5, <= 5 trials) — adil_regularized.py:315-501.  Returns (D, v).
+
+    Upstream bookkeeping is reproduced exactly (quirk Q13 and neighbours): v.grad and D.grad are never zeroed, so the
+    V-step uses the gradient accumulated over every earlier backward pass, grad_D at the end of an epoch is the sum
+    of all D-pass gradients plus the V-pass gradients from the 2nd batch on (:450, :461); the V backtracking result is
+    discarded and only shrinks stepsize_v (:442-446, :460); inside the probe the l1 term is not scaled by lambda (:439)."""
+    device = torch.device(device)
+    nimg = len(dataset)
+    x0, _ = next(iter(dataset))
+    nc, nx, ny = x0.shape
+    delta, beta = .5, .5
+    loader = torch.utils.data.DataLoader(dataset, batch_size=batchsize, shuffle=False)
+    coeff = 1. if targeted else -1.
+    indices = get_slices(nimg, batchsize)
+    stepsize_D = stepsize_v = stepsize
+    criterion = nn.CrossEntropyLoss(reduction='sum')
+    if init_dictionary is not None:
+        D = init_dictionary.to(device=device, dtype=torch.float32).contiguous().clone()
+    else:
+        D = constraint_dict(torch.randn(3, nx, ny, n_atom, device=device), constr_set=dict_set)      # :358-359
+    v = torch.zeros(nimg, n_atom, device=device)
+    grad_v_acc, grad_D_acc = torch.zeros_like(v), torch.zeros_like(D)
+    d_tracks = False
+    label, pred = [], []
+
+    def loss_all(vec, Dict):
+        with torch.no_grad():
+            return (_smooth_loss(model, loader, Dict, vec, indices, coeff, l2_fool, targeted, criterion, device)
+                    + lambdaCoding * torch.sum(torch.abs(vec))).item()
+
+    def batch_smooth(x, tgt, ind, vec, Dict):
+        xt = ops.dict_synth(x, Dict, vec, ind)
+        return coeff * criterion(model(xt), tgt) + .5 * l2_fool * torch.sum((xt - x) ** 2)
+
+    loss = [loss_all(v, D)]
+    for i_bar in range(int(nepochs)):
+        i_max = 0
+        for bi, (x, y) in enumerate(loader):
+            x, y = x.to(device=device), y.to(device=device)
+            ind = torch.as_tensor(indices[bi], dtype=torch.int64, device=device)
+            if i_bar == 0:
+                label = label + y.tolist()
+                pred = pred + model(x).sort().indices[:, -1].tolist()
+            tgt = get_target(x, y, targeted, model)
+            # ---------- V pass (:393-416)
+            vg = v.detach().requires_grad_(True)
+            Dg = D.detach().requires_grad_(d_tracks)
+            ls = batch_smooth(x, tgt, ind, vg, Dg)
+            if d_tracks:
+                gv, gD = torch.autograd.grad(ls, [vg, Dg])
+                grad_D_acc += gD
+            else:
+                (gv,) = torch.autograd.grad(ls, vg)
+            grad_v_acc += gv
+            with torch.no_grad():
+                v_old = v[ind].clone()
+                loss_batch_old = (ls.detach() + lambdaCoding * torch.sum(torch.abs(v_old))).item()
+                rows = v_old.clone()
+                ops.ista_step_(rows, grad_v_acc[ind].contiguous(), stepsize_v, stepsize_v * lambdaCoding)
+                v[ind] = rows
+                # ---------- backtracking probe (:419-446)
+                v_cur = rows.clone()
+                loss_batch_cur = (batch_smooth(x, tgt, ind, v, D) + lambdaCoding * torch.sum(torch.abs(v_cur))).item()
+                loss_batch_cur_0 = loss_batch_cur
+                delta_h = (torch.sum(grad_v_acc[ind] * (v_cur - v_old))
+                           + 1 / 2 / stepsize_v * torch.norm(v_cur - v_old) ** 2).item()
+                i = 0
+                while loss_batch_cur > loss_batch_old + delta_h * beta and i < 5:
+                    i += 1
+                    v[ind] = (delta ** i) * v_cur + (1 - delta ** i) * v_old
+                    loss_batch_cur = (batch_smooth(x, tgt, ind, v, D) + torch.sum(torch.abs(v[ind]))).item()
+                    delta_h = delta_h * delta
+                if not (loss_batch_cur_0 <= loss_batch_cur):
+                    i_max = max(i, i_max)
+                v[ind] = v_cur
+            # ---------- D pass (:448-458)
+            d_tracks = True
+            vg = v.detach().requires_grad_(True)
+            Dg = D.detach().requires_grad_(True)
+            gv, gD = torch.autograd.grad(batch_smooth(x, tgt, ind, vg, Dg), [vg, Dg])
+            grad_v_acc += gv
+            grad_D_acc += gD
+        stepsize_v = max(stepsize_v * (delta ** i_max), 1e-5)
+        grad_D = grad_D_acc
+        if torch.max(torch.abs(grad_D)).item() < 1e-4:
+            continue
+        D_old = D.detach().clone()
+        loss_i_old = loss_all(v, D_old)
+        with torch.no_grad():
+            D_cur = constraint_dict((D - stepsize_D * grad_D).contiguous(), constr_set=dict_set)
+            loss_i_cur = loss_all(v, D_cur)
+            loss_i_cur_0 = loss_i_cur
+            delta_h_D = (torch.sum(grad_D * (D_cur - D_old)) + 1 / 2 / stepsize_D * torch.norm(D_cur - D_old) ** 2).item()
+            i = 0
+            while loss_i_cur > loss_i_old + delta_h_D * beta and i < 5:
+                i += 1
+                loss_i_cur = loss_all(v, ((delta ** i) * D_cur + (1 - delta ** i) * D_old).contiguous())
+                delta_h_D = delta_h_D * delta
+            if loss_i_cur_0 <= loss_i_cur:
+                loss.append(loss_i_cur_0)
+            else:
+                stepsize_D = max(stepsize_D * delta ** i, 1e-6)
+                loss.append(loss_i_cur)
+            D = D_cur                                            # fresh tensor upstream: its gradient sum restarts
+            grad_D_acc = torch.zeros_like(D)
+            d_tracks = False
+        if abs(loss[-1] - loss[-2]) < 1e-6:
+            break
+    if model_file is not None:
+        torch.save([D, label, pred, v, loss], model_file)        # :499
+    return D, v
+
+
 class ADILR(Attack):
     """Kept importable for `from attacks import ADILR` (attacks/__init__.py:1).  Upstream the constructor always
     raises TypeError (adil_regularized.py:689 vs :722); use ADIL, or the functions of this module."""

@@ -662,3 +662,104 @@ def performance(attack_fn: Callable[[Tensor, Tensor], Tensor], model, batches: S
         rmse += compute_rmse(adv, x)
         mse += compute_mse(adv, x)
     return dict(fooling_rate=fooling / num, rmse=rmse / num, mse=mse / num, num_samples=num)
+
+
+def sadil_updated(model, images: Tensor, labels: Tensor, d0: Tensor, targeted: bool = True, nepochs: int = 3,
+                  batchsize: int = 1, lambda_coding: float = 1.0, l2_fool: float = 1.0, stepsize: float = 1.0,
+                  dict_set: str = "l2ball"):
+    """sadil_updated() (adil_regularized.py:315-501): per-batch ISTA step on the codes with a backtracking probe, one
+    dictionary step per epoch with a line search (delta = beta = .5, <= 5 trials each).
+
+    Upstream quirks reproduced (Q13 and neighbours):
+      * v is one leaf whose .grad is never zeroed: the V-step uses the gradient accumulated over EVERY earlier
+        backward pass (both passes of every batch, all epochs) (:405-416);
+      * D.requires_grad is switched on at the end of each batch (:450), so from the 2nd batch of an epoch on the
+        V-pass backward also accumulates into D.grad; grad_D at the end of the epoch (:461) is that whole sum; D is
+        re-created by the update, so the sum restarts per epoch unless the epoch `continue`s (:463-464);
+      * the V backtracking result is discarded (both branches restore v_cur, :442-446), only i_max survives and
+        shrinks stepsize_v (:460); inside the probe loop the l1 term is NOT scaled by lambda (:439).
+    Returns (D, v, loss)."""
+    n_img, k = images.shape[0], d0.shape[-1]
+    delta, beta = 0.5, 0.5
+    coeff = 1.0 if targeted else -1.0
+    batches = get_slices(n_img, batchsize)
+    stepsize_d, stepsize_v = stepsize, stepsize
+    d, v = d0.clone(), torch.zeros(n_img, k)
+    grad_v_acc = torch.zeros_like(v)
+    grad_d_acc = torch.zeros_like(d)
+    d_tracks = False                                             # D.requires_grad of the current D tensor
+
+    def total_loss(vv, dd):
+        with torch.no_grad():
+            return float(_smooth_loss(model, images, labels, dd, vv, batches, coeff, l2_fool, targeted)) \
+                + float(lambda_coding * vv.abs().sum())
+
+    def batch_smooth(vv, dd, idx):
+        return _smooth_loss(model, images, labels, dd, vv, [idx], coeff, l2_fool, targeted)
+
+    loss = [total_loss(v, d)]
+    for _ in range(int(nepochs)):
+        i_max = 0
+        for idx in batches:
+            # ---- V pass (:393-416)
+            vg = v.detach().requires_grad_(True)
+            dg = d.detach().requires_grad_(d_tracks)
+            ls = batch_smooth(vg, dg, idx)
+            if d_tracks:
+                gv, gd = torch.autograd.grad(ls, [vg, dg])
+                grad_d_acc += gd
+            else:
+                (gv,) = torch.autograd.grad(ls, vg)
+            grad_v_acc += gv
+            v_old = v[idx].clone()
+            loss_batch_old = float(ls.detach() + lambda_coding * v[idx].abs().sum())
+            with torch.no_grad():
+                v[idx] = softshrink(v[idx] - stepsize_v * grad_v_acc[idx], stepsize_v * lambda_coding)
+                # ---- backtracking probe (:419-446)
+                v_cur = v[idx].clone()
+                loss_batch_cur = float(batch_smooth(v, d, idx) + lambda_coding * v[idx].abs().sum())
+                loss_batch_cur_0 = loss_batch_cur
+                delta_h = float((grad_v_acc[idx] * (v_cur - v_old)).sum() + 0.5 / stepsize_v * (v_cur - v_old).norm() ** 2)
+                i = 0
+                while loss_batch_cur > loss_batch_old + delta_h * beta and i < 5:
+                    i += 1
+                    v[idx] = (delta ** i) * v_cur + (1 - delta ** i) * v_old
+                    loss_batch_cur = float(batch_smooth(v, d, idx) + v[idx].abs().sum())
+                    delta_h = delta_h * delta
+                if not (loss_batch_cur_0 <= loss_batch_cur):
+                    i_max = max(i, i_max)
+                v[idx] = v_cur
+            # ---- D pass (:448-458)
+            d_tracks = True
+            vg = v.detach().requires_grad_(True)
+            dg = d.detach().requires_grad_(True)
+            gv, gd = torch.autograd.grad(batch_smooth(vg, dg, idx), [vg, dg])
+            grad_v_acc += gv
+            grad_d_acc += gd
+        stepsize_v = max(stepsize_v * (delta ** i_max), 1e-5)
+        grad_d = grad_d_acc
+        if float(grad_d.abs().max()) < 1e-4:
+            continue
+        d_old = d.clone()
+        loss_i_old = total_loss(v, d_old)
+        with torch.no_grad():
+            d_cur = constraint_dict(d - stepsize_d * grad_d, dict_set)
+            loss_i_cur = total_loss(v, d_cur)
+            loss_i_cur_0 = loss_i_cur
+            delta_h_d = float((grad_d * (d_cur - d_old)).sum() + 0.5 / stepsize_d * (d_cur - d_old).norm() ** 2)
+            i = 0
+            while loss_i_cur > loss_i_old + delta_h_d * beta and i < 5:
+                i += 1
+                loss_i_cur = total_loss(v, (delta ** i) * d_cur + (1 - delta ** i) * d_old)
+                delta_h_d = delta_h_d * delta
+            if loss_i_cur_0 <= loss_i_cur:
+                loss.append(loss_i_cur_0)
+            else:
+                stepsize_d = max(stepsize_d * delta ** i, 1e-6)
+                loss.append(loss_i_cur)
+            d = d_cur                                            # fresh tensor: its gradient sum restarts
+            grad_d_acc = torch.zeros_like(d)
+            d_tracks = False
+        if abs(loss[-1] - loss[-2]) < 1e-6:
+            break
+    return d, v, loss

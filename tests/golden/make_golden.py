@@ -453,10 +453,35 @@ def g12_ista_and_metrics():
     save("g12_ista_metrics", images=images, labels=labels, d=d, lam=0.05, lcv_lambda_l1=2.0, step=0.05, **state_to_npz_dict(net), **out)
 
 
+def g13_sadil_updated():
+    g = torch.Generator().manual_seed(113)
+    n, k = 6, 4
+    images = torch.rand(n, 3, 16, 16, generator=g)
+    net = make_tinynet(1113)
+    labels = net(images).argmax(-1)
+    ds = U.QuickAttackDataset(images, labels)
+    out = {}
+    for tag, step, lam in (("a", 0.05, 0.05), ("b", 0.5, 0.3)):      # b: the line searches actually trigger
+        with scratch_cwd():
+            torch.manual_seed(31)
+            d_, v_ = quiet(R.sadil_updated, ds, net, targeted=True, nepochs=3, batchsize=2, lambdaCoding=lam, l2_fool=0.05,
+                           stepsize=step, n_atom=k, model_file="su.bin")
+            saved = torch.load("su.bin")
+        torch.manual_seed(31)
+        d0 = U.constraint_dict(torch.randn(3, 16, 16, k), "l2ball")
+        od, ov, ol = O.sadil_updated(net, images, labels, d0, True, 3, 2, lam, 0.05, step)
+        e1 = close(od, d_, 5e-5, "sadil_updated D"); e2 = close(ov, v_, 5e-5, "sadil_updated V")
+        close(ol, saved[4], 1e-3, "sadil_updated loss")
+        print(f"  g13[{tag}] err D {e1:.2e} V {e2:.2e} loss {saved[4]}")
+        out.update({f"{tag}_d0": d0, f"{tag}_d": d_.detach(), f"{tag}_v": v_.detach(), f"{tag}_loss": np.array(saved[4]),
+                    f"{tag}_step": step, f"{tag}_lam": lam})
+    save("g13_sadil_updated", images=images, labels=labels, l2=0.05, **state_to_npz_dict(net), **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (g1_l1ball, g2_constraints, g3_softshrink, g4_synth_grad, g5_floss, g6_adamw_steps, g7_learn_a,
-               g8_learn_b, g9_ddrague, g10_adamw_inference, g11_unsupervised, g12_ista_and_metrics):
+               g8_learn_b, g9_ddrague, g10_adamw_inference, g11_unsupervised, g12_ista_and_metrics, g13_sadil_updated):
         if only and fn.__name__.split("_")[0] not in only:
             continue
         print(fn.__name__)

@@ -174,6 +174,23 @@ def test_ista_family_golden():
     close(d, z["sadil_d"], 2e-4, "sadil D"); close(v, z["sadil_v"], 2e-4, "sadil V")
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_sadil_updated_golden(tag, tmp_path):
+    from attacks.attacks_classes.adil_regularized import sadil_updated
+    from attacks.utils import QuickAttackDataset
+    z = load_golden("g13_sadil_updated")
+    net = net_on_gpu(z)
+    ds = QuickAttackDataset(t(z["images"]), t(z["labels"]))
+    out = str(tmp_path / "su.bin")
+    d, v = sadil_updated(ds, net, targeted=True, nepochs=3, batchsize=2, lambdaCoding=float(z[f"{tag}_lam"]),
+                         l2_fool=float(z["l2"]), stepsize=float(z[f"{tag}_step"]), n_atom=4, device=DEV, model_file=out,
+                         init_dictionary=t(z[f"{tag}_d0"]))
+    close(d, z[f"{tag}_d"], 5e-4, "D"); close(v, z[f"{tag}_v"], 5e-4, "V")
+    saved = torch.load(out, map_location="cpu")
+    assert len(saved) == 5 and len(saved[1]) == len(ds)                   # [D, label, pred, v, loss] (:499)
+    close(saved[4], z[f"{tag}_loss"], 2e-3 * float(np.abs(z[f"{tag}_loss"]).max()))
+
+
 def test_performance_metrics_golden():
     import performance as perf
     z = load_golden("g12_ista_metrics")

@@ -166,3 +166,12 @@ def test_g12_ista_and_metrics():
     close(perf["fooling_rate"], z["perf_fooling_rate"], 1e-6)
     close(perf["rmse"], z["perf_rmse"], 1e-6)
     close(perf["mse"], z["perf_mse"], 1e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g13_sadil_updated(tag):
+    z = load_golden("g13_sadil_updated")
+    net = tinynet_from_npz(z)
+    d, v, loss = O.sadil_updated(net, t(z["images"]), t(z["labels"]), t(z[f"{tag}_d0"]), True, 3, 2, float(z[f"{tag}_lam"]),
+                                 float(z["l2"]), float(z[f"{tag}_step"]))
+    close(d, z[f"{tag}_d"], 5e-5); close(v, z[f"{tag}_v"], 5e-5); close(loss, z[f"{tag}_loss"], 1e-3)
