@@ -32,6 +32,10 @@ SIGNATURES = {
     "adil_gram": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "adil_dict_rightmul": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "adil_image_metrics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "adil_affine_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int,
+                                    c_void_p]),
+    "adil_affine_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int,
+                                    c_void_p]),
 }
 
 ABI_VERSION = 1

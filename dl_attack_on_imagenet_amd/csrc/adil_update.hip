@@ -510,3 +510,149 @@ extern "C" int adil_image_metrics(const void* adv, const void* x, int B, int P, 
     ADIL_CHECK_LAUNCH();
     return 0;
 }
+
+// =========================================================================== //
+// Frozen-classifier epilogues: eval-mode BatchNorm (per-channel scale/shift) + optional residual + optional ReLU
+// in ONE pass, forward and input-gradient backward.  Not part of the ADiL maths — they only remove elementwise
+// passes PyTorch would run as separate kernels around every convolution of the frozen network (bias/BN, add, ReLU).
+// Channel of flat element i is (i / inner) % C: inner = 1 for channels_last storage, H*W for contiguous NCHW.
+// =========================================================================== //
+// LAYOUT 0: channels_last (channel = i % C, the VEC elements of a thread are VEC consecutive channels, C % VEC == 0)
+// LAYOUT 1: NCHW          (channel = (i / inner) % C, constant over the VEC elements, inner % VEC == 0)
+// LAYOUT 2: anything else (per-element index arithmetic)
+template <int VEC, int LAYOUT>
+__device__ __forceinline__ void channel_params(const float* __restrict__ tab, size_t base, int C, int inner, float (&o)[VEC]) {
+    if (LAYOUT == 0) {
+        const float4* p = reinterpret_cast<const float4*>(tab + (base % (size_t)C));
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) { const float4 t = p[q]; o[4 * q] = t.x; o[4 * q + 1] = t.y; o[4 * q + 2] = t.z; o[4 * q + 3] = t.w; }
+    } else if (LAYOUT == 1) {
+        const float t = tab[(base / (size_t)inner) % (size_t)C];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = t;
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = tab[((base + j) / (size_t)inner) % (size_t)C];
+    }
+}
+
+template <typename T, int VEC> struct ActVec;
+template <> struct ActVec<float, 4> {
+    static __device__ __forceinline__ void load(const float* p, size_t i, float (&o)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, size_t i, const float (&o)[4]) {
+        *reinterpret_cast<float4*>(p + i) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+};
+template <> struct ActVec<bf16_t, 8> {
+    static __device__ __forceinline__ void load(const bf16_t* p, size_t i, float (&o)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p + i);
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { o[2 * q] = __uint_as_float(w[q] << 16); o[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, size_t i, const float (&o)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = (unsigned)f32_to_bf16(o[2 * q]) | ((unsigned)f32_to_bf16(o[2 * q + 1]) << 16);
+        *reinterpret_cast<uint4*>(p + i) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+template <typename T, int VEC, int LAYOUT>
+__global__ __launch_bounds__(256) void affine_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, T* __restrict__ y,
+                                                             size_t n, int C, int inner, int relu) {
+    const size_t nv = n / VEC;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        const size_t base = i * VEC;
+        float v[VEC], sc[VEC], sh[VEC];
+        ActVec<T, VEC>::load(x, base, v);
+        channel_params<VEC, LAYOUT>(scale, base, C, inner, sc);
+        channel_params<VEC, LAYOUT>(shift, base, C, inner, sh);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
+        if (res != nullptr) {                                    // uniform
+            float r[VEC];
+            ActVec<T, VEC>::load(res, base, r);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[j] += r[j];
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[j] = fmaxf(v[j], 0.0f);
+        }
+        ActVec<T, VEC>::store(y, base, v);
+    }
+}
+
+// gx = mask * g * scale[c];  gres (optional) = mask * g;  mask = (y > 0) if relu else 1
+template <typename T, int VEC, int LAYOUT>
+__global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                             const float* __restrict__ scale, T* __restrict__ gx,
+                                                             T* __restrict__ gres, size_t n, int C, int inner, int relu) {
+    const size_t nv = n / VEC;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        const size_t base = i * VEC;
+        float gv[VEC], sc[VEC];
+        ActVec<T, VEC>::load(g, base, gv);
+        channel_params<VEC, LAYOUT>(scale, base, C, inner, sc);
+        if (relu) {                                              // uniform
+            float yv[VEC];
+            ActVec<T, VEC>::load(y, base, yv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) gv[j] = (yv[j] > 0.0f) ? gv[j] : 0.0f;
+        }
+        if (gres != nullptr) ActVec<T, VEC>::store(gres, base, gv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) gv[j] *= sc[j];
+        ActVec<T, VEC>::store(gx, base, gv);
+    }
+}
+
+static inline int act_layout(size_t n, int C, int inner, int vec) {
+    if (inner == 1 && C % vec == 0) return 0;
+    if (inner % vec == 0) return 1;
+    return 2;
+}
+
+#define ADIL_ACT_DISPATCH(KERNEL, T, VEC, ...)                                                                      \
+    do {                                                                                                            \
+        const int lay = act_layout(n, C, inner, VEC);                                                               \
+        const dim3 grid(stream_grid(n / VEC, 256)), block(256);                                                     \
+        if (lay == 0) hipLaunchKernelGGL((KERNEL<T, VEC, 0>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);     \
+        else if (lay == 1) hipLaunchKernelGGL((KERNEL<T, VEC, 1>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<T, VEC, 2>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);              \
+    } while (0)
+
+extern "C" int adil_affine_act_fwd(const void* x, const void* res, const float* scale, const float* shift, void* y,
+                                   size_t n, int C, int inner, int relu, int dtype, void* stream) {
+    ADIL_ENTER();
+    if (!x || !scale || !shift || !y || n == 0 || C <= 0 || inner <= 0 || (n % 8) != 0) return ADIL_EINVAL;
+    if (dtype == ADIL_F32)
+        ADIL_ACT_DISPATCH(affine_act_fwd_kernel, float, 4, (const float*)x, (const float*)res, scale, shift, (float*)y, n, C, inner, relu);
+    else if (dtype == ADIL_BF16)
+        ADIL_ACT_DISPATCH(affine_act_fwd_kernel, bf16_t, 8, (const bf16_t*)x, (const bf16_t*)res, scale, shift, (bf16_t*)y, n, C, inner, relu);
+    else
+        return ADIL_EINVAL;
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_affine_act_bwd(const void* g, const void* y, const float* scale, void* gx, void* gres, size_t n,
+                                   int C, int inner, int relu, int dtype, void* stream) {
+    ADIL_ENTER();
+    if (!g || !scale || !gx || n == 0 || C <= 0 || inner <= 0 || (n % 8) != 0 || (relu && !y)) return ADIL_EINVAL;
+    if (dtype == ADIL_F32)
+        ADIL_ACT_DISPATCH(affine_act_bwd_kernel, float, 4, (const float*)g, (const float*)y, scale, (float*)gx, (float*)gres, n, C, inner, relu);
+    else if (dtype == ADIL_BF16)
+        ADIL_ACT_DISPATCH(affine_act_bwd_kernel, bf16_t, 8, (const bf16_t*)g, (const bf16_t*)y, scale, (bf16_t*)gx, (bf16_t*)gres, n, C, inner, relu);
+    else
+        return ADIL_EINVAL;
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}

@@ -293,6 +293,61 @@ def image_metrics(adv: Tensor, x: Tensor) -> Tuple[Tensor, Tensor]:
 
 
 # --------------------------------------------------------------------------- #
+def _channel_inner(t: Tensor) -> int:
+    """Stride pattern of a 4-d activation: 1 for channels_last storage, H*W for contiguous NCHW."""
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous():
+        return 1
+    if t.is_contiguous():
+        return t.shape[2] * t.shape[3] if t.dim() == 4 else 1
+    raise ValueError("activation must be contiguous (NCHW) or channels_last")
+
+
+class AffineActFunction(torch.autograd.Function):
+    """y = act(x * scale[c] + shift[c] (+ res)) in one pass; backward gives the INPUT gradients only (the classifier is
+    frozen).  Replaces eval-BatchNorm + residual add + ReLU of a frozen conv block (see zoo.fuse_bn_act_)."""
+
+    @staticmethod
+    def forward(ctx, x, res, scale, shift, relu):
+        lib = _lib.load()
+        _dev(scale, "scale", torch.float32)
+        _dev(shift, "shift", torch.float32)
+        inner = _channel_inner(x)
+        if res is not None and (res.shape != x.shape or _channel_inner(res) != inner or res.dtype != x.dtype):
+            res = res.to(x.dtype).contiguous(memory_format=torch.channels_last if inner == 1 else torch.contiguous_format)
+        y = torch.empty_like(x)
+        _lib.check(lib.adil_affine_act_fwd(_ptr(x), _ptr(res), _ptr(scale), _ptr(shift), _ptr(y), x.numel(), x.shape[1],
+                                           inner, int(relu), stream_dtype_code(x.dtype), _stream()), "adil_affine_act_fwd")
+        ctx.save_for_backward(y if relu else None, scale)
+        ctx.meta = (inner, bool(relu), res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        y, scale = ctx.saved_tensors
+        inner, relu, has_res = ctx.meta
+        ref = y if y is not None else g
+        if _channel_inner_or_none(g) != inner:
+            g = g.contiguous(memory_format=torch.channels_last if inner == 1 else torch.contiguous_format)
+        gx = torch.empty_like(g)
+        gres = torch.empty_like(g) if has_res else None
+        _lib.check(lib.adil_affine_act_bwd(_ptr(g), _ptr(y), _ptr(scale), _ptr(gx), _ptr(gres), g.numel(), g.shape[1], inner,
+                                           int(relu), stream_dtype_code(g.dtype), _stream()), "adil_affine_act_bwd")
+        return gx, gres, None, None, None
+
+
+def _channel_inner_or_none(t: Tensor):
+    try:
+        return _channel_inner(t)
+    except ValueError:
+        return None
+
+
+def affine_act(x: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = None, relu: bool = True) -> Tensor:
+    return AffineActFunction.apply(x, res, scale, shift, relu)
+
+
+# --------------------------------------------------------------------------- #
 class DictSynthFunction(torch.autograd.Function):
     """x + D v[index] as a differentiable op (the tensordot of adil.py:25 and its autograd backward).
     grad wrt v is dense (N,K) with zero rows outside `index`, exactly what autograd produces."""

@@ -371,11 +371,73 @@ def pad_first_conv_(net: nn.Module, width: int = 8) -> nn.Module:
     return net
 
 
+def _bn_affine(bn: nn.BatchNorm2d):
+    """Eval-mode BatchNorm as a per-channel affine map: y = x * scale + shift (fp32 buffers)."""
+    with torch.no_grad():
+        scale = (bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)).float()
+        shift = (bn.bias.double() - bn.running_mean.double() * scale.double()).float()
+    return scale.contiguous(), shift.contiguous()
+
+
+class _ConvAffine(nn.Module):
+    """conv (weights untouched) followed by the fused eval-BatchNorm [+ residual] [+ ReLU] epilogue kernel."""
+
+    def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool):
+        super().__init__()
+        self.conv, self.relu = conv, relu
+        scale, shift = _bn_affine(bn)
+        self.register_buffer('scale', scale)
+        self.register_buffer('shift', shift)
+
+    def forward(self, x, res=None):
+        from . import ops
+        return ops.affine_act(self.conv(x), self.scale.float(), self.shift.float(), res=res, relu=self.relu)
+
+
+class _FusedResBlock(nn.Module):
+    def __init__(self, block):
+        super().__init__()
+        self.bottleneck = isinstance(block, Bottleneck)
+        self.c1 = _ConvAffine(block.conv1, block.bn1, True)
+        if self.bottleneck:
+            self.c2 = _ConvAffine(block.conv2, block.bn2, True)
+            self.c3 = _ConvAffine(block.conv3, block.bn3, True)          # + residual, then ReLU
+        else:
+            self.c2 = _ConvAffine(block.conv2, block.bn2, True)          # + residual, then ReLU
+        self.down = None if block.downsample is None else _ConvAffine(block.downsample[0], block.downsample[1], False)
+
+    def forward(self, x):
+        idt = x if self.down is None else self.down(x)
+        out = self.c1(x)
+        if self.bottleneck:
+            return self.c3(self.c2(out), res=idt)
+        return self.c2(out, res=idt)
+
+
+class FusedResNet(nn.Module):
+    """A frozen ResNet whose BatchNorm(eval) / residual add / ReLU run as ONE elementwise kernel per convolution
+    (`ops.affine_act`, forward and input-gradient backward) instead of 2-3 separate PyTorch kernels.  Convolution
+    weights are untouched; the function is the original network's (up to one rounding per activation).  GPU only."""
+
+    def __init__(self, net: ResNet):
+        super().__init__()
+        self.stem = _ConvAffine(net.conv1, net.bn1, True)
+        self.maxpool = net.maxpool
+        self.layers = nn.Sequential(*[_FusedResBlock(b) for layer in (net.layer1, net.layer2, net.layer3, net.layer4)
+                                      for b in layer])
+        self.avgpool, self.fc = net.avgpool, net.fc
+
+    def forward(self, x):
+        x = self.layers(self.maxpool(self.stem(x)))
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
 def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights: Optional[str] = None,
                      device=None, dtype: torch.dtype = torch.float32, channels_last: bool = False,
-                     fold_bn: bool = False, pad_input_channels: int = 0) -> nn.Module:
+                     fold_bn: bool = False, pad_input_channels: int = 0, fuse_bn_act: bool = False) -> nn.Module:
     """Sequential(Normalize, net), eval mode, parameters frozen — the object both CLIs hand to ADIL.
-    fold_bn / pad_input_channels apply the function-preserving rewrites above (off by default)."""
+    fold_bn / pad_input_channels / fuse_bn_act apply the function-preserving rewrites above (off by default);
+    fuse_bn_act (ResNets, GPU only) supersedes fold_bn."""
     key = canonical_name(name)
     with torch.random.fork_rng(devices=[]):
         torch.manual_seed(seed)
@@ -383,7 +445,9 @@ def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights:
     if weights is not None:
         net.load_state_dict(torch.load(weights, map_location='cpu'))
     net.eval()
-    if fold_bn:
+    if fuse_bn_act and isinstance(net, ResNet):
+        net = FusedResNet(net)
+    elif fold_bn:
         fold_batchnorm_(net)
     model = nn.Sequential(Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225]), net)
     model.eval()
@@ -392,6 +456,9 @@ def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights:
     model = model.to(device=device, dtype=dtype)
     if channels_last:
         model = model.to(memory_format=torch.channels_last)
+    for m in model.modules():                                # epilogue tables stay fp32 whatever the activation dtype
+        if isinstance(m, _ConvAffine):
+            m.scale, m.shift = m.scale.float(), m.shift.float()
     if pad_input_channels:
         pad_first_conv_(net, pad_input_channels)
     return model

@@ -122,6 +122,17 @@ int adil_dict_rightmul(const float* d, const float* mat, int P, int K, float* ou
 int adil_image_metrics(const void* adv, const void* x, int B, int P, int dtype, float* sq_err, float* sq_norm,
                        void* stream);
 
+/* Frozen-classifier epilogues (NOT part of the ADiL maths; no reference counterpart — they replace the separate
+ * BatchNorm(eval) / add / ReLU kernels PyTorch launches around each convolution of the frozen network, e.g. the
+ * torchvision ResNet blocks the reference builds at demo_dL_attack.py:41-59):
+ *     y = act( x * scale[c] + shift[c] (+ res) ),  act = ReLU if relu else identity
+ *     gx = mask * g * scale[c],  gres = mask * g  (mask = y > 0 if relu else 1)     [input gradient only: frozen net]
+ * channel of flat element i is (i / inner) % C  (inner = 1 for channels_last storage, H*W for NCHW); n % 8 == 0. */
+int adil_affine_act_fwd(const void* x, const void* res, const float* scale, const float* shift, void* y, size_t n, int C,
+                        int inner, int relu, int dtype, void* stream);
+int adil_affine_act_bwd(const void* g, const void* y, const float* scale, void* gx, void* gres, size_t n, int C,
+                        int inner, int relu, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

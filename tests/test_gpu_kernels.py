@@ -301,3 +301,59 @@ def test_errors_are_loud():
     with pytest.raises(TypeError):
         o.synth(torch.zeros(2, 3, 4, 4, device=DEV, dtype=torch.float16), torch.zeros(3, 4, 4, 2, device=DEV),
                 torch.zeros(32, 16, device=DEV), 2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cl", [False, True])
+def test_affine_act_epilogue(dt, cl):
+    """Fused eval-BatchNorm + residual + ReLU epilogue (frozen-classifier helper) vs plain torch ops, fwd and bwd."""
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(4, 16, 6, 10, generator=gen).to(DEV).to(dt)
+    res = torch.randn(4, 16, 6, 10, generator=gen).to(DEV).to(dt)
+    if cl:
+        x, res = x.contiguous(memory_format=torch.channels_last), res.contiguous(memory_format=torch.channels_last)
+    scale = (torch.rand(16, generator=gen) + 0.5).to(DEV)
+    shift = torch.randn(16, generator=gen).to(DEV)
+    for use_res, relu in ((True, True), (False, True), (False, False)):
+        xa = x.clone().requires_grad_(True)
+        ra = res.clone().requires_grad_(True)
+        y = ops().affine_act(xa, scale, shift, res=ra if use_res else None, relu=relu)
+        xb = x.clone().float().requires_grad_(True)
+        rb = res.clone().float().requires_grad_(True)
+        ref = xb * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        if use_res:
+            ref = ref + rb
+        if relu:
+            ref = torch.relu(ref)
+        tol = 1e-5 if dt == torch.float32 else 3e-2
+        close(y.float(), ref, tol)
+        gout = torch.randn(y.shape, generator=gen).to(DEV)
+        y.backward(gout.to(dt).contiguous(memory_format=torch.channels_last) if cl else gout.to(dt))
+        ref.backward(gout.to(dt).float())
+        mask = (y.float() == 0) & relu                      # ReLU boundary elements may round to either side in bf16
+        close(torch.where(mask, torch.zeros_like(xb.grad), xa.grad.float() - xb.grad), torch.zeros_like(xb.grad), tol)
+        if use_res:
+            close(torch.where(mask, torch.zeros_like(rb.grad), ra.grad.float() - rb.grad), torch.zeros_like(rb.grad), tol)
+
+
+def test_fused_resnet_matches_plain():
+    from dl_attack_on_imagenet_amd import zoo
+    plain = zoo.build_classifier("resnet18", num_classes=10, seed=4, device=DEV)
+    g = torch.Generator().manual_seed(1)
+    for m in plain.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    fused = torch.nn.Sequential(plain[0], zoo.FusedResNet(plain[1])).to(DEV)
+    for m in fused.modules():
+        if isinstance(m, zoo._ConvAffine):
+            m.scale, m.shift = m.scale.float().to(DEV), m.shift.float().to(DEV)
+    x = torch.rand(4, 3, 64, 64, generator=g).to(DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = plain(xa), fused(xb)
+    close(yb, ya, 1e-4 * float(ya.abs().max()))
+    ga, = torch.autograd.grad(ya.sum(), xa)
+    gb, = torch.autograd.grad(yb.sum(), xb)
+    assert float((ga - gb).norm() / ga.norm()) < 1e-3
