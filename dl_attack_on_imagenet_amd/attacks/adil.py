@@ -302,6 +302,8 @@ class ADIL(Attack):
                 f"The adversarial dictionary {self.model_file} has not been learned: construct ADIL with "
                 "data_train=... first (the reference's fallback calls a method that does not exist, adil.py:442)")
         d = self._load_dictionary()
+        if images.shape[0] == 0:                             # e.g. performance() kept no correctly classified sample
+            return images.clone() if self.attack == 'supervised' else (images.clone(), [])
         if self.attack == 'supervised':
             return self.forward_supervised_DDrague(images, labels, d)
         return self.forward_unsupervised(images)

@@ -284,6 +284,9 @@ def image_metrics(adv: Tensor, x: Tensor) -> Tuple[Tensor, Tensor]:
     _dev(adv, "adv")
     _dev(x, "x", adv.dtype)
     b = x.shape[0]
+    if b == 0:                                                   # empty batch (e.g. nothing correctly classified): empty sums
+        z = torch.zeros(0, dtype=torch.float32, device=x.device)
+        return z, z.clone()
     p = x.numel() // b
     se = torch.empty(b, dtype=torch.float32, device=x.device)
     sn = torch.empty(b, dtype=torch.float32, device=x.device)

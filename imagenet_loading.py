@@ -22,6 +22,10 @@ class Subset_I(Subset):
         x, y = super().__getitem__(item)
         return (item, x, y) if self.indexed else (x, y)
 
+    def __getitems__(self, items):
+        # torch >= 2.1 DataLoaders fetch a Subset through __getitems__, which would bypass the indexed protocol
+        return [self[i] for i in items]
+
 
 def dataset_split_by_class(dataset, number_per_class, number_of_classes=1000, samples_per_class=50):
     """Class-balanced train/val/test split (imagenet_loading.py:21-44): per class, shuffle its images with the

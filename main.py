@@ -32,6 +32,7 @@ def build_parser():
     p.add_argument('--image', default=DEFAULT_IMAGE)
     p.add_argument('--weights', default=None)
     p.add_argument('--synthetic', action='store_true', help='attack a seeded random image instead of a JPEG')
+    p.add_argument('--image-size', type=int, default=224, help='side of the synthetic image (must match the dictionary)')
     p.add_argument('--figure', default='attack_samples.png')
     return p
 
@@ -45,7 +46,7 @@ def main(args):
     model_name = zoo.canonical_name(args.model)
     model = zoo.build_classifier(model_name, weights=args.weights, device=device)
     if args.synthetic:
-        im = torch.rand(3, 224, 224, generator=torch.Generator().manual_seed(0))
+        im = torch.rand(3, args.image_size, args.image_size, generator=torch.Generator().manual_seed(0))
     else:
         im = load_image(args.image)
     eps = 8 / 255

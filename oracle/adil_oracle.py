@@ -56,7 +56,7 @@ def project_onto_l1_ball(x: Tensor, eps: float) -> Tensor:
     j = torch.arange(1, k + 1, device=x2.device)
     cond = (mu * j > (csum - eps))
     rho = (cond * j).max(dim=1).values                       # in [0, k]; 0 only if no j satisfies
-    theta = (csum[torch.arange(n), rho - 1] - eps) / rho     # rho==0 -> index -1, /0 (reference behaviour)
+    theta = (csum[torch.arange(n, device=x2.device), rho - 1] - eps) / rho     # rho==0 -> index -1, /0 (reference behaviour)
     proj = (absx - theta.unsqueeze(1)).clamp(min=0)
     out = inside * x2 + (1 - inside) * proj * torch.sign(x2)
     return out.reshape(shape)
@@ -194,7 +194,7 @@ def f_loss(outputs: Tensor, labels: Tensor, kappa: float, targeted: bool = False
     branch because it reads torchattacks' `_targeted` (False)."""
     one_hot = torch.eye(outputs.shape[1], device=outputs.device)[labels]
     i = ((1 - one_hot) * outputs).max(dim=1).values
-    j = outputs[torch.arange(outputs.shape[0]), labels]
+    j = outputs[torch.arange(outputs.shape[0], device=outputs.device), labels]
     if targeted:
         return (i - j).clamp(min=-kappa)
     return (j - i).clamp(min=-kappa)
@@ -265,7 +265,7 @@ def learn_dictionary_a(model, images: Tensor, d0: Tensor, v0: Tensor, epochs_bat
     for it, batches in enumerate(epochs_batches):
         loss_full, fooled = 0.0, 0
         for idx in batches:
-            index = torch.as_tensor(idx, dtype=torch.long)
+            index = torch.as_tensor(idx, dtype=torch.long, device=images.device)
             ls, fl = learn_step_a(model, images[index], index, d, v, opt_d, opt_v, eps, loss, coeff, kappa)
             loss_full += ls
             fooled += fl

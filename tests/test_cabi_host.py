@@ -158,6 +158,10 @@ def test_dataset_protocol_and_split():
     i, x2, y2 = tr[0]
     assert i == 0 and torch.equal(x, x2) and y == y2
     assert isinstance(tr, Subset_I)
+    batch = next(iter(torch.utils.data.DataLoader(tr, batch_size=4, shuffle=False)))      # the path ADIL uses
+    assert len(batch) == 3 and batch[0].tolist() == [0, 1, 2, 3] and batch[1].shape == (4, 3, 8, 8)
+    tr.indexed = False
+    assert len(next(iter(torch.utils.data.DataLoader(tr, batch_size=4)))) == 2
 
 
 def test_adil_constructor_surface_without_data(tmp_path):

@@ -231,3 +231,48 @@ def test_end_to_end_round_trip_full_size(tmp_path):
     adv = atk(images[:8].to(DEV), torch.zeros(8, dtype=torch.long, device=DEV))
     assert adv.shape == (8, 3, 224, 224) and float(adv.min()) >= 0 and float(adv.max()) <= 1
     assert torch.isfinite(adv).all()
+
+
+def test_config1_resnet18_parity():
+    """BASELINE.json configs[0]: resnet18, 32 images of 3x224x224, 10 atoms, 20 inner iterations, fp32 — the
+    reference's own CPU-runnable case.  HIP learner (GPU) vs the CPU oracle on identical seeded inputs.
+
+    Two levels, because the 20-iteration trajectory of a ReLU network under AdamW is chaotic in the last bits: the SAME
+    oracle code run on CPU and on GPU tensors (only the classifier backend differs: MKL vs MIOpen, dLoss/dx equal to
+    1e-6 relative) ends 0.1 apart in 30 % of the dictionary entries (tools/exp_parity.py).  So (a) every single step
+    from an identical state must agree tightly, (b) the trajectory must agree in what the attack is about: fooling
+    counts and loss."""
+    from dl_attack_on_imagenet_amd import engine, zoo
+    from oracle import adil_oracle as O
+    n, k, T, eps = 32, 10, 20, 8 / 255
+    g = torch.Generator().manual_seed(21)
+    images = torch.rand(n, 3, 224, 224, generator=g)
+    d0 = -1 + 2 * torch.rand(3, 224, 224, k, generator=g)
+    v0 = O.project_onto_l1_ball(torch.rand(n, k, generator=g), eps)
+    cpu_model = zoo.build_classifier("resnet18", seed=5)
+    gpu_model = zoo.build_classifier("resnet18", seed=5, device=DEV)
+    index = torch.arange(n)
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    od, ov = d0.clone(), v0.clone()
+    sd, sv = O.AdamWState(od, 0.01), O.AdamWState(ov, 0.01)
+    learner = engine.DictionaryLearner(d0.to(DEV), v0.to(DEV), eps, 0.01, "logits", False, 50.0)
+    x_gpu = images.to(DEV)
+    fooled_cpu, fooled_gpu, loss_cpu, loss_gpu = [], [], [], []
+    for it in range(T):
+        ls, fl = O.learn_step_a(cpu_model, images, index, od, ov, sd, sv, eps, "logits", -1.0, 50.0)
+        loss_cpu.append(ls); fooled_cpu.append(fl)
+        ls, fl = learner.step(gpu_model, x_gpu, index.to(DEV))
+        loss_gpu.append(float(ls)); fooled_gpu.append(int(fl))
+        if it == 0:                                               # (a) one step from the identical state
+            dd = (learner.d.cpu() - od).abs()
+            e_v = float((learner.v.cpu() - ov).abs().max())
+            flips = float((dd > 1e-4).float().mean())             # first AdamW step = lr*sign(g): flips where g ~ 0
+            print("config1 step-1: |dD| median %.2e, entries off by > 1e-4: %.2e, |dV| %.2e" % (float(dd.median()), flips, e_v))
+            assert float(dd.median()) <= 1e-6 and flips <= 1e-3 and e_v <= 1e-5
+            assert fooled_cpu == fooled_gpu and abs(loss_cpu[0] - loss_gpu[0]) <= 1e-4 * max(1.0, abs(loss_cpu[0]))
+    print("config1 trajectory: fooled cpu %s gpu %s" % (fooled_cpu, fooled_gpu))
+    # (b) trajectory: fooling counts within one image at every iteration, equal at the end; loss within 2 %
+    assert max(abs(a - b) for a, b in zip(fooled_cpu, fooled_gpu)) <= 1
+    assert fooled_cpu[-1] == fooled_gpu[-1]
+    assert max(abs(a - b) for a, b in zip(loss_cpu, loss_gpu)) <= 2e-2 * max(abs(a) for a in loss_cpu)
+    assert float((learner.v.cpu() - ov).abs().max()) <= 5e-3      # codes stay close (l1 radius 0.031)

@@ -1,0 +1,25 @@
+"""Per-step GPU time breakdown from a rocprofv3 kernel trace of bench.py (steady-state step between two synth launches)."""
+import collections, csv, glob, re, sys
+path = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+rows = list(csv.DictReader(open(path)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(rows) if 'synth_mfma_kernel' in r['Kernel_Name']]
+def short(n):
+    n = n.strip('"')
+    for key, lab in (('batch_norm', 'batch_norm'), ('conv_bwd_data', 'conv_bwd_data'), ('igemm_bwd', 'conv_bwd_data'), ('conv_fwd', 'conv_fwd'),
+                     ('igemm_fwd', 'conv_fwd'), ('direct_copy', 'copy'), ('CUDAFunctor_add', 'add'), ('SubTensorOp', 'miopen_subtensor(zero/bias)'),
+                     ('threshold', 'relu_bwd'), ('clamp', 'relu/clamp'), ('max_pool', 'maxpool'), ('affine_act_fwd', 'affine_act_fwd'),
+                     ('affine_act_bwd', 'affine_act_bwd'), ('batched_transpose', 'miopen_transpose'), ('fillBuffer', 'memset')):
+        if key in n: return lab
+    m = re.match(r'(?:void )?([\w:]+)', n); return (m.group(1) if m else n)[:44]
+a, b = idx[-3], idx[-2]
+seg = rows[a:b]
+wall = int(rows[b]['Start_Timestamp']) - int(rows[a]['Start_Timestamp'])
+busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in seg)
+print(f"step: {len(seg)} kernels, wall {wall/1e6:.2f} ms, busy {busy/1e6:.2f} ms")
+agg, cnt = collections.Counter(), collections.Counter()
+for r in seg:
+    k = short(r['Kernel_Name']); agg[k] += int(r['End_Timestamp']) - int(r['Start_Timestamp']); cnt[k] += 1
+for k, v in agg.most_common(18): print(f"{k:44s} {cnt[k]:5d} {v/1e6:8.3f} ms")
+big = sorted(seg, key=lambda r: int(r['End_Timestamp']) - int(r['Start_Timestamp']), reverse=True)[:8]
+for r in big: print(f"  {(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3:9.1f} us  {short(r['Kernel_Name'])}  grid {r['Grid_Size_X']}")
