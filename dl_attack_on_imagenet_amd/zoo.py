@@ -174,15 +174,26 @@ class _MLPBlock(nn.Sequential):
 class _EncoderBlock(nn.Module):
     def __init__(self, heads, dim, mlp_dim):
         super().__init__()
+        self.heads = heads
         self.ln_1 = nn.LayerNorm(dim, eps=1e-6)
-        self.self_attention = nn.MultiheadAttention(dim, heads, batch_first=True)
+        self.self_attention = nn.MultiheadAttention(dim, heads, batch_first=True)   # parameter container (torchvision names)
         self.ln_2 = nn.LayerNorm(dim, eps=1e-6)
         self.mlp = _MLPBlock(dim, mlp_dim)
 
+    def _attention(self, y):
+        """Plain-matmul self attention with the MultiheadAttention parameters.  The fused SDPA / native-MHA kernels of
+        this PyTorch-ROCm build raised a GPU memory access fault on ViT-B/16 (197 tokens, bf16), so they are not used."""
+        att = self.self_attention
+        b, t, dim = y.shape
+        hd = dim // self.heads
+        qkv = F.linear(y, att.in_proj_weight, att.in_proj_bias).reshape(b, t, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]                                   # (b, heads, t, hd)
+        w = torch.softmax((q @ k.transpose(-1, -2)) * (hd ** -0.5), dim=-1)
+        out = (w @ v).permute(0, 2, 1, 3).reshape(b, t, dim)
+        return F.linear(out, att.out_proj.weight, att.out_proj.bias)
+
     def forward(self, x):
-        y = self.ln_1(x)
-        y, _ = self.self_attention(y, y, y, need_weights=False)
-        x = x + y
+        x = x + self._attention(self.ln_1(x))
         return x + self.mlp(self.ln_2(x))
 
 
