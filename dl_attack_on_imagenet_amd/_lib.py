@@ -20,6 +20,8 @@ SIGNATURES = {
                           c_size_t, c_void_p]),
     "adil_adamw_clamp": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,
                                  c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "adil_zstep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
+                           c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "adil_adamw_l1ball": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
                                   c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "adil_l1ball_project": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),

@@ -49,6 +49,26 @@ __device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
     atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
 }
 
+// --------------------------------------------------------------------------- //
+// AdamW (torch.optim.AdamW single-tensor semantics) on one element
+// --------------------------------------------------------------------------- //
+struct AdamWHyper {
+    float decay;      // 1 - lr*wd
+    float b1, b2;     // betas
+    float eps;
+    float step_size;  // lr / (1 - b1^t)
+    float bc2_sqrt;   // sqrt(1 - b2^t)
+};
+
+__device__ __forceinline__ float adamw_elem(float p, float g, float& m, float& s, const AdamWHyper& h) {
+    p *= h.decay;
+    m = m + (1.0f - h.b1) * (g - m);                 // exp_avg.lerp_(grad, 1-b1)
+    s = s * h.b2 + (1.0f - h.b2) * g * g;            // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+    float denom = sqrtf(s) / h.bc2_sqrt + h.eps;
+    return p - h.step_size * (m / denom);
+}
+
+
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // hipGetLastError is sticky per thread: drop whatever an earlier, unrelated HIP call (e.g. PyTorch's lazy device

@@ -275,6 +275,94 @@ __global__ __launch_bounds__(256) void synth_mfma_kernel(const T* __restrict__ x
 }
 
 // =========================================================================================================== //
+// K8  fused inference step of forward_supervised_DDrague (adil.py:551-559):  the gradient wrt z,
+//     gz = (dL/dv) D_dagger  (same contraction as the synthesis, vp := packed dL/dv, d := D_dagger^T),
+// is formed in the MFMA accumulators and consumed on the spot by AdamW(z) + clamp(+-eps) + max|dz| — it is never
+// written to HBM.  Same workgroup / fragment layout as synth_mfma_kernel; z, m, s are fp32 B x P.
+// =========================================================================================================== //
+template <bool FAST>
+__global__ __launch_bounds__(256) void zstep_mfma_kernel(float* __restrict__ z, float* __restrict__ m,
+                                                         float* __restrict__ sq, const float* __restrict__ d,
+                                                         const float* __restrict__ vp, int B, int P, int K, int Kp,
+                                                         AdamWHyper hy, float lo, float hi, float* max_abs_delta,
+                                                         int tile0) {
+    using M = Mma<float>;
+    using Frag = M::Frag;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* sd = reinterpret_cast<float*>(smem_raw);
+    const int Ks = Kp + M::PAD;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    const int p0 = (tile0 + blockIdx.x) * SYNTH_TILE;
+    for (int i0 = tid; i0 < SYNTH_TILE * Kp; i0 += 256 * 8) {
+        float val[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 256 * u;
+            const int r = i / Kp, k = i - r * Kp;
+            const int p = p0 + r;
+            const float ok = ((p < P) && (k < K)) ? 1.0f : 0.0f;
+            val[u] = d[(size_t)(p < P ? p : P - 1) * K + (k < K ? k : K - 1)] * ok;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 256 * u;
+            const int r = i / Kp, k = i - r * Kp;
+            sd[((r & 3) * 32 + (r >> 2)) * Ks + k] = val[u];
+        }
+    }
+    __syncthreads();
+    const int NG = Kp >> 4;
+    const int nbb = (B + 31) >> 5;
+    const int px = p0 + 4 * c;
+    float dmax = 0.0f;
+    for (int bb = w; bb < nbb; bb += 4) {
+        const int b0 = bb << 5;
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        const float* arow = vp + (size_t)(b0 + c) * Kp + 8 * h;
+        Frag a = frag_from_f32x8<float>(arow);
+        for (int g = 0; g < NG; ++g) {
+            const int gn = (g + 1 < NG) ? g + 1 : g;
+            const Frag an = frag_from_f32x8<float>(arow + 16 * gn);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const Frag bf = M::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h);
+                M::mma(acc[t], a, bf);
+            }
+            a = an;
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = b0 + c_row(reg, h);
+            const size_t ro = (size_t)(row < B ? row : B - 1) * P;        // rows >= B: valid address, never stored
+            float zv[4], mv[4], sv[4];
+            load_px<float, 4, FAST>(z + ro, px, P, zv);
+            load_px<float, 4, FAST>(m + ro, px, P, mv);
+            load_px<float, 4, FAST>(sq + ro, px, P, sv);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float q = adamw_elem(zv[t], acc[t][reg], mv[t], sv[t], hy);
+                q = fminf(fmaxf(q, lo), hi);
+                if (row < B && (FAST || px + t < P)) dmax = fmaxf(dmax, fabsf(q - zv[t]));
+                zv[t] = q;
+            }
+            if (row < B) {
+                store_px4<float, FAST>(z + ro, px, P, zv);
+                store_px4<float, FAST>(m + ro, px, P, mv);
+                store_px4<float, FAST>(sq + ro, px, P, sv);
+            }
+        }
+    }
+    if (max_abs_delta != nullptr) {
+        dmax = wave_max(dmax);
+        if (lane == 0 && dmax > 0.0f) atomic_max_nonneg(max_abs_delta, dmax);
+    }
+}
+
+// =========================================================================================================== //
 // K3  grad_d = g^T vp.  Each WAVE owns pixel tiles of PXT*32 pixels and sweeps all batch rows; the grad_d tile
 // (PXT*32 px x AT*32 atoms) lives in the accumulators for the whole sweep.  A = g^T read in the coalesced
 // "lane = PXT consecutive pixels, 8 batch rows per lane" layout (PXT*64 contiguous bytes per row and half-wave),
@@ -1025,4 +1113,34 @@ extern "C" int adil_grad(const void* g, const float* d, const float* vp, float* 
     if (dtype == ADIL_F32) return launch_grad<float>(g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, (hipStream_t)stream);
     if (dtype == ADIL_BF16) return launch_grad<bf16_t>(g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, (hipStream_t)stream);
     return ADIL_EINVAL;
+}
+
+template <bool FAST>
+static int launch_zstep_range(float* z, float* m, float* sq, const float* d, const float* vp, int B, int P, int K,
+                              AdamWHyper hy, float lo, float hi, float* max_abs_delta, int tile0, int ntiles,
+                              hipStream_t st) {
+    if (ntiles <= 0) return 0;
+    const int Kp = round_up(K, 16);
+    const size_t lds = (size_t)SYNTH_TILE * (Kp + Mma<float>::PAD) * sizeof(float);
+    int rc = set_lds((const void*)zstep_mfma_kernel<FAST>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((zstep_mfma_kernel<FAST>), dim3(ntiles), dim3(256), lds, st, z, m, sq, d, vp, B, P, K, Kp, hy, lo, hi,
+                       max_abs_delta, tile0);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, const float* gvp, int B, int P, int K,
+                          float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi,
+                          float* max_abs_delta, void* stream) {
+    ADIL_ENTER();
+    if (!z || !m || !s || !dpinv_t || !gvp || B <= 0 || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
+    AdamWHyper hy{decay, b1, b2, eps, step_size, bc2_sqrt};
+    const bool vec = (P % 4 == 0) && ((((uintptr_t)z | (uintptr_t)m | (uintptr_t)s) % 16) == 0);
+    const int ntiles = (P + SYNTH_TILE - 1) / SYNTH_TILE;
+    const int nfast = vec ? P / SYNTH_TILE : 0;
+    int rc = launch_zstep_range<true>(z, m, s, dpinv_t, gvp, B, P, K, hy, lo, hi, max_abs_delta, 0, nfast, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_zstep_range<false>(z, m, s, dpinv_t, gvp, B, P, K, hy, lo, hi, max_abs_delta, nfast, ntiles - nfast,
+                                     (hipStream_t)stream);
 }

@@ -3,25 +3,6 @@
 // elementwise / row-wise work: 16-byte vector accesses, one pass per stream.
 #include "adil_common.h"
 
-// --------------------------------------------------------------------------- //
-// AdamW (torch.optim.AdamW single-tensor semantics) on one element
-// --------------------------------------------------------------------------- //
-struct AdamWHyper {
-    float decay;      // 1 - lr*wd
-    float b1, b2;     // betas
-    float eps;
-    float step_size;  // lr / (1 - b1^t)
-    float bc2_sqrt;   // sqrt(1 - b2^t)
-};
-
-__device__ __forceinline__ float adamw_elem(float p, float g, float& m, float& s, const AdamWHyper& h) {
-    p *= h.decay;
-    m = m + (1.0f - h.b1) * (g - m);                 // exp_avg.lerp_(grad, 1-b1)
-    s = s * h.b2 + (1.0f - h.b2) * g * g;            // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-    float denom = sqrtf(s) / h.bc2_sqrt + h.eps;
-    return p - h.step_size * (m / denom);
-}
-
 // ---- K4 / K8: flat AdamW + clamp[lo,hi] (+ max|delta|) --------------------- //
 template <typename GT>
 __global__ __launch_bounds__(256) void adamw_clamp_kernel(float* __restrict__ p, const GT* __restrict__ g,

@@ -215,7 +215,6 @@ def solve_ddrague(model, images: Tensor, d: Tensor, eps: float, steps_inference:
     if labels is None:
         labels = predict(model, images)                                                  # adil.py:539 (constant)
     delta = torch.zeros(1, dtype=torch.float32, device=images.device)
-    gz = torch.empty_like(z)
     iters = 0
 
     def codes_of(zz):
@@ -228,9 +227,9 @@ def solve_ddrague(model, images: Tensor, d: Tensor, eps: float, steps_inference:
         xt = ops.synth(images, d, vp, b)                                                 # adil.py:543-544
         _, _, g = input_gradient(model, xt, labels, loss, coeff, kappa, "mean")
         _, gv = ops.grad(g, d, None, b, want_d=False, want_v=True)                       # dL/dv = g D
-        ops.synth(None, dpt, ops.pack_codes(gv, None, b), b, out=gz)                     # dL/dz = (dL/dv) D_dagger
         delta.zero_()
-        ops.adamw_clamp_(z, gz, m, s, sched.next(), -eps, eps, max_abs_delta=delta)       # adil.py:554-555 (K8)
+        # dL/dz = (dL/dv) D_dagger is formed inside the kernel and consumed by AdamW(z) + clamp: never materialised (K8)
+        ops.zstep_(z, m, s, dpt, ops.pack_codes(gv, None, b), b, sched.next(), -eps, eps, max_abs_delta=delta)
         if float(delta) < 1e-6:                                                          # adil.py:559
             break
     vcode = codes_of(z)

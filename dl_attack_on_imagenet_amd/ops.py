@@ -179,6 +179,21 @@ def adamw_clamp_(p: Tensor, g: Tensor, m: Tensor, s: Tensor, h: AdamWScalars, lo
                                     _ptr(max_abs_delta), _stream()), "adil_adamw_clamp")
 
 
+def zstep_(z: Tensor, m: Tensor, s: Tensor, dpinv_t: Tensor, gvp: Tensor, batch: int, h: AdamWScalars, lo: float,
+           hi: float, max_abs_delta: Optional[Tensor] = None) -> None:
+    """In-place fused DDrague step: gz = gvp D_dagger formed on the fly, AdamW(z), clamp, max|dz| (adil.py:551-559)."""
+    lib = _lib.load()
+    for name, t in (("z", z), ("m", m), ("s", s), ("dpinv_t", dpinv_t), ("gvp", gvp)):
+        _dev(t, name, torch.float32)
+    p, k = dict_shape(dpinv_t)
+    if not (z.numel() == m.numel() == s.numel() == batch * p) or gvp.shape != (_round_up(batch, 32), _round_up(k, 16)):
+        raise ValueError("zstep_: operand shapes do not match (B, P, K)")
+    if max_abs_delta is not None:
+        _dev(max_abs_delta, "max_abs_delta", torch.float32)
+    _lib.check(lib.adil_zstep(_ptr(z), _ptr(m), _ptr(s), _ptr(dpinv_t), _ptr(gvp), batch, p, k, h.decay, h.b1, h.b2, h.eps,
+                              h.step_size, h.bc2_sqrt, float(lo), float(hi), _ptr(max_abs_delta), _stream()), "adil_zstep")
+
+
 def adamw_l1ball_(v: Tensor, grad_vb: Tensor, pos: Optional[Tensor], m: Tensor, s: Tensor, h: AdamWScalars,
                   radius: float, max_abs_delta: Optional[Tensor] = None) -> None:
     """In-place AdamW on ALL rows of v (zero gradient outside the batch) + l1-ball projection

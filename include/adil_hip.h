@@ -82,6 +82,15 @@ int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, float* s, s
                      float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi,
                      float* max_abs_delta, void* stream);
 
+/* Fused inference step of forward_supervised_DDrague (adil.py:551-559): the gradient wrt z,
+ *     gz = gvp D_dagger   (gvp = packed dLoss/dv [Bp][Kp], dpinv_t = D_dagger^T stored P x K like D),
+ * is formed in the MFMA accumulators and consumed on the spot by AdamW(z) + clamp[lo,hi] + max|dz|; it never
+ * touches HBM.  z, m, s are fp32 B x P.  Replaces `loss.backward()` through the two tensordots (adil.py:542-543),
+ * `optimise.step()`, the clamp (adil.py:555) and the stop test (adil.py:559). */
+int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, const float* gvp, int B, int P, int K, float decay,
+               float b1, float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi, float* max_abs_delta,
+               void* stream);
+
 /* Fused AdamW step on ALL N rows of the code matrix + row-wise l1-ball projection.
  * The gradient is non-zero only for the rows of the current batch: pos[n] = b if row n is
  * batch slot b (gradient row grad_vb[b]), -1 otherwise (zero gradient; the row still

@@ -357,3 +357,33 @@ def test_fused_resnet_matches_plain():
     ga, = torch.autograd.grad(ya.sum(), xa)
     gb, = torch.autograd.grad(yb.sum(), xb)
     assert float((ga - gb).norm() / ga.norm()) < 1e-3
+
+
+@pytest.mark.parametrize("shape", [(5, 3, 7, 9, 3), (33, 3, 16, 16, 10), (64, 3, 32, 32, 50), (40, 3, 8, 8, 100)])
+def test_zstep_fused_vs_unfused(shape):
+    """K8: gz = gv D_dagger formed inside the kernel + AdamW(z) + clamp + max|dz| against the explicit sequence."""
+    b, c, h, w, k = shape
+    gen = torch.Generator().manual_seed(sum(shape) + 7)
+    dpt = torch.randn(c, h, w, k, generator=gen) * 0.1
+    gv = torch.randn(b, k, generator=gen)
+    z0 = torch.randn(b, c, h, w, generator=gen) * 0.01
+    eps = 0.02
+    zr, st = z0.clone(), O.AdamWState(z0, 1e-2)
+    zf = z0.clone().to(DEV)
+    mf, sf = torch.zeros_like(zf), torch.zeros_like(zf)
+    sched = ops().AdamWSchedule(1e-2)
+    delta = torch.zeros(1, device=DEV)
+    for it in range(3):
+        gz = (gv.double() @ dpt.reshape(-1, k).double().t()).float().reshape(z0.shape) * (0.5 ** it)
+        prev = zr.clone()
+        st.step(zr, gz)
+        zr.clamp_(-eps, eps)
+        delta.zero_()
+        ops().zstep_(zf, mf, sf, dpt.to(DEV), ops().pack_codes((gv * 0.5 ** it).to(DEV), None, b), b, sched.next(), -eps, eps,
+                     max_abs_delta=delta)
+        # the first AdamW steps are ~ lr*g/(|g|+1e-8): elements with |gz| ~ 1e-7 amplify the fp32-vs-fp64 rounding of
+        # gz, so the bound is 5e-5 on the max and 1e-7 on the mean
+        close(zf, zr, 5e-5, f"z it {it}")
+        assert float((zf.cpu() - zr).abs().mean()) <= 1e-7
+        assert abs(float(delta) - float((zr - prev).abs().max())) <= 5e-5
+    close(mf, st.m, 1e-5); close(sf, st.v, 1e-5)
