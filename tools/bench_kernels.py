@@ -38,3 +38,22 @@ m, sq = torch.zeros_like(d), torch.zeros_like(d)
 h = ops.AdamWSchedule(0.01).next()
 gd = torch.randn_like(d)
 t = timeit(lambda: ops.adamw_clamp_(d, gd, m, sq, h, -1.0, 1.0)); print(f"adamw_clamp(D)  {t*1e3:9.1f} us  {7*P*K*4/t/1e6:8.1f} GB/s")
+
+# ---- one inference iteration of forward_supervised_DDrague (dictionary path only, fp32 z as the reference)
+from dl_attack_on_imagenet_amd import engine
+x32 = torch.rand(B, 3, S, S, generator=g0).to(dev)
+g32 = torch.randn(B, 3, S, S, generator=g0).to(dev)
+z = (torch.randn(B, 3, S, S, generator=g0) * 0.01).to(dev)
+mz, sz = torch.zeros_like(z), torch.zeros_like(z)
+pinv = engine.PseudoInverse(d)
+dpt = pinv.d_pinv_t
+hz = ops.AdamWSchedule(1e-2).next()
+def iteration():
+    _, vc = ops.grad(z, dpt, None, B, want_d=False)            # v = z D_dagger^T
+    xt = ops.synth(x32, d, ops.pack_codes(vc, None, B), B)      # x + D v
+    _, gv = ops.grad(g32, d, None, B, want_d=False)            # dL/dv = g D
+    ops.zstep_(z, mz, sz, dpt, ops.pack_codes(gv, None, B), B, hz, -8 / 255, 8 / 255)
+t = timeit(iteration, n=10)
+alg = 9 * B * P * 4 + 4 * P * K * 4
+print(f"DDrague iteration (fp32, dictionary path) {t*1e3:9.1f} us  {alg/t/1e6:8.1f} GB/s algorithmic ({alg/1e9:.2f} GB)")
+t = timeit(lambda: engine.PseudoInverse(d), n=5); print(f"Gram + inverse + D_dagger (once per attack call) {t*1e3:9.1f} us")
