@@ -15,6 +15,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native 16-byte register quad (HIP's uint4 struct resists SROA)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <typename T> struct Mma;
@@ -133,6 +134,56 @@ __device__ __forceinline__ void store_px4(T* rowp, int px, int P, const float (&
             if (px + i < P) Elem<T>::store(rowp, px + i, o[i]);
     }
 }
+// ---- buffer addressing for the aligned interior ------------------------------------------------------------- //
+// 4 consecutive pixels of a 32-row batch block through raw buffer instructions: ONE per-lane byte offset (voffset)
+// plus a wave-uniform row offset (soffset, an SGPR) per access, against a descriptor whose num_records ends at row
+// B.  Compared with 64-bit flat addresses this frees the ~2 VGPRs per outstanding access that the 16 loads + 16
+// stores of a block cost, and rows >= B need no branch: out-of-range loads return 0, out-of-range stores are dropped.
+typedef __amdgpu_buffer_rsrc_t buf_rsrc;
+__device__ __forceinline__ buf_rsrc block_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+template <typename T> struct BufPx;
+template <> struct BufPx<float> {
+    typedef u32x4 Raw;
+    static __device__ __forceinline__ Raw load(buf_rsrc r, int voff, int soff) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    }
+    static __device__ __forceinline__ void unpack(const Raw& t, float (&o)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __uint_as_float(t[i]);
+    }
+    // buffer_store_dwordx4 + explicit wait states.  The hardware reads store data wider than 64 bits some cycles after
+    // issue, and hipcc's hazard recogniser exempts MUBUF stores with an SGPR soffset from the wait state it inserts
+    // for that.  Measured on gfx950 without the s_nop: under load the NEXT row's values (written to the same VGPRs
+    // right after the store issues) land in memory.  The sched_barriers pin store -> s_nop -> next VALU write.
+    static __device__ __forceinline__ void store(buf_rsrc r, int voff, int soff, const float (&o)[4]) {
+        Raw t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = __float_as_uint(o[i]);
+        __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+template <> struct BufPx<bf16_t> {
+    typedef u32x2 Raw;
+    static __device__ __forceinline__ Raw load(buf_rsrc r, int voff, int soff) {
+        return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    }
+    static __device__ __forceinline__ void unpack(const Raw& t, float (&o)[4]) {
+        o[0] = __uint_as_float(t[0] << 16); o[1] = __uint_as_float(t[0] & 0xffff0000u);
+        o[2] = __uint_as_float(t[1] << 16); o[3] = __uint_as_float(t[1] & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void store(buf_rsrc r, int voff, int soff, const float (&o)[4]) {
+        Raw t;
+        t[0] = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+        t[1] = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+        __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
+    }
+};
+
 // 8 consecutive pixels of one row as an MFMA fragment (the A operand of grad_v)
 template <typename T, bool FAST>
 __device__ __forceinline__ typename Mma<T>::Frag load_frag8(const T* rowp, int px, int P) {
@@ -239,8 +290,104 @@ __device__ __forceinline__ void synth_sweep(const T* __restrict__ x, const float
     }
 }
 
+template <typename T, bool XACC, bool PIXCLAMP>
+__device__ __forceinline__ void synth_store_buf(const f32x16 (&acc)[4], buf_rsrc rx, buf_rsrc ro, int voff, unsigned rowb,
+                                                float delta_clamp) {
+    using BP = BufPx<T>;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int soff = (int)((unsigned)c_row(reg, 0) * rowb);
+        float r[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r[t] = acc[t][reg];
+        if (!XACC) {
+            if (delta_clamp >= 0.0f) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) r[t] = fminf(fmaxf(r[t], -delta_clamp), delta_clamp);
+            }
+            float xv[4];
+            BP::unpack(BP::load(rx, voff, soff), xv);                                     // x == NULL: empty buffer -> 0
+#pragma unroll
+            for (int t = 0; t < 4; ++t) r[t] += xv[t];
+        }
+        if (PIXCLAMP) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) r[t] = fminf(fmaxf(r[t], 0.0f), 1.0f);
+        }
+        BP::store(ro, voff, soff, r);
+    }
+}
+
+// Aligned-interior sweep (FAST tiles): buffer addressing (see BufPx) and the code fragments of the first
+// SYNTH_HOIST k-groups loaded up front, BEFORE the 16 x loads, so that per batch block a wave pays one L2 round trip
+// for its codes (hidden under the HBM latency of x) instead of one per k-group in the MFMA loop.
+#define SYNTH_HOIST 4
+template <typename T, bool XACC>
+__device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const float* __restrict__ vp,
+                                                T* __restrict__ out, const typename Mma<T>::Elem* sd, int B, int P,
+                                                int Kp, int Ks, int p0, float delta_clamp, int pixel_clamp, int w, int c,
+                                                int h) {
+    using M = Mma<T>;
+    using Frag = typename M::Frag;
+    using BP = BufPx<T>;
+    const int NG = Kp >> 4;
+    const int nbb = (B + 31) >> 5;
+    const unsigned rowb = (unsigned)P * (unsigned)sizeof(T);
+    const int voff = (int)((unsigned)(4 * h) * rowb) + (p0 + 4 * c) * (int)sizeof(T);
+    for (int bb = w; bb < nbb; bb += 4) {
+        const int b0 = bb << 5;
+        const int rows = B - b0 < 32 ? B - b0 : 32;
+        const buf_rsrc rx = block_rsrc(x ? x + (size_t)b0 * P : nullptr, x ? (unsigned)rows * rowb : 0u);
+        const buf_rsrc ro = block_rsrc(out + (size_t)b0 * P, (unsigned)rows * rowb);
+        const float* arow = vp + (size_t)(b0 + c) * Kp + 8 * h;
+        float4 araw[SYNTH_HOIST][2];
+#pragma unroll
+        for (int g = 0; g < SYNTH_HOIST; ++g) {
+            const float* ap = arow + 16 * (g < NG ? g : NG - 1);
+            araw[g][0] = *reinterpret_cast<const float4*>(ap);
+            araw[g][1] = *reinterpret_cast<const float4*>(ap + 4);
+        }
+        typename BP::Raw xr[16];
+        if (XACC) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) xr[reg] = BP::load(rx, voff, (int)((unsigned)c_row(reg, 0) * rowb));
+        }
+        Frag a[SYNTH_HOIST];
+#pragma unroll
+        for (int g = 0; g < SYNTH_HOIST; ++g) {
+            const float f[8] = {araw[g][0].x, araw[g][0].y, araw[g][0].z, araw[g][0].w,
+                                araw[g][1].x, araw[g][1].y, araw[g][1].z, araw[g][1].w};
+            a[g] = M::from8(f);
+        }
+        f32x16 acc[4];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            float xv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (XACC) BP::unpack(xr[reg], xv);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t][reg] = xv[t];
+        }
+#pragma unroll
+        for (int g = 0; g < SYNTH_HOIST; ++g) {
+            if (g < NG) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) M::mma(acc[t], a[g], M::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h));
+            }
+        }
+        for (int g = SYNTH_HOIST; g < NG; ++g) {                                         // K > 64
+            const Frag ag = frag_from_f32x8<T>(arow + 16 * g);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) M::mma(acc[t], ag, M::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h));
+        }
+        if (pixel_clamp)                                                                  // uniform: one branch per block
+            synth_store_buf<T, XACC, true>(acc, rx, ro, voff, rowb, delta_clamp);
+        else
+            synth_store_buf<T, XACC, false>(acc, rx, ro, voff, rowb, delta_clamp);
+    }
+}
+
 template <typename T, bool XACC, bool FAST>
-__global__ __launch_bounds__(256) void synth_mfma_kernel(const T* __restrict__ x, const float* __restrict__ d,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void synth_mfma_kernel(const T* __restrict__ x, const float* __restrict__ d,
                                                          const float* __restrict__ vp, T* __restrict__ out, int B,
                                                          int P, int K, int Kp, float delta_clamp, int pixel_clamp,
                                                          int tile0) {
@@ -251,27 +398,65 @@ __global__ __launch_bounds__(256) void synth_mfma_kernel(const T* __restrict__ x
     const int Ks = Kp + M::PAD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int p0 = (tile0 + blockIdx.x) * SYNTH_TILE;
-    // D slice -> LDS.  SYNTH_TILE*Kp/256 = Kp/2 elements per thread, a multiple of 8: eight independent loads are
-    // issued before the first conversion (a rolled loop would pay one full memory latency per element)
-    for (int i0 = tid; i0 < SYNTH_TILE * Kp; i0 += 256 * 8) {
-        float val[8];
+    if constexpr (FAST) {
+        // D slice -> LDS.  The slice (128 pixels x K atoms) is one contiguous, 16-byte aligned run of 32*K float4:
+        // every thread issues up to 8 independent 16-byte loads before the first conversion, so the fill costs ONE
+        // memory round trip for K <= 64 (a scalar-load loop pays one per 8 elements and keeps the workgroup's wave
+        // slots idle for a third of its life).
+        const float4* src = reinterpret_cast<const float4*>(d + (size_t)p0 * K);
+        const int nq = 32 * K;
+        const float rk = 1.0f / (float)K;
+        for (int q0 = tid; q0 < nq; q0 += 256 * 8) {
+            float4 val[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 256 * u;
-            const int r = i / Kp, k = i - r * Kp;
-            const int p = p0 + r;
-            const float ok = ((p < P) && (k < K)) ? 1.0f : 0.0f;
-            val[u] = d[(size_t)(p < P ? p : P - 1) * K + (k < K ? k : K - 1)] * ok;
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + 256 * u;
+                val[u] = src[q < nq ? q : nq - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + 256 * u;
+                if (q < nq) {
+                    const int i = 4 * q;
+                    int r = (int)(((float)i + 0.5f) * rk);           // i / K, exact: |error| << 0.5 / K for i < 2^14
+                    int k = i - r * K;
+                    const float e4[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sd[((r & 3) * 32 + (r >> 2)) * Ks + k] = M::to_elem(e4[e]);
+                        if (++k == K) { k = 0; ++r; }
+                    }
+                }
+            }
         }
+        for (int k = K + (tid & 1); k < Kp; k += 2)                   // zero the padded atoms of row tid/2
+            sd[(((tid >> 1) & 3) * 32 + (tid >> 3)) * Ks + k] = M::to_elem(0.0f);
+    } else {
+        // element-wise fill with pixel / atom guards: eight independent loads are issued before the first conversion
+        for (int i0 = tid; i0 < SYNTH_TILE * Kp; i0 += 256 * 8) {
+            float val[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 256 * u;
-            const int r = i / Kp, k = i - r * Kp;
-            sd[((r & 3) * 32 + (r >> 2)) * Ks + k] = M::to_elem(val[u]);
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u;
+                const int r = i / Kp, k = i - r * Kp;
+                const int p = p0 + r;
+                const float ok = ((p < P) && (k < K)) ? 1.0f : 0.0f;
+                val[u] = d[(size_t)(p < P ? p : P - 1) * K + (k < K ? k : K - 1)] * ok;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u;
+                const int r = i / Kp, k = i - r * Kp;
+                sd[((r & 3) * 32 + (r >> 2)) * Ks + k] = M::to_elem(val[u]);
+            }
         }
     }
     __syncthreads();
-    synth_sweep<T, XACC, FAST>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp, w, c, h);
+    if constexpr (FAST)
+        synth_sweep_buf<T, XACC>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp,
+                                 __builtin_amdgcn_readfirstlane(w), c, h);
+    else
+        synth_sweep<T, XACC, FAST>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp, w, c, h);
 }
 
 // =========================================================================================================== //
@@ -881,7 +1066,8 @@ static int launch_synth_range(const void* x, const float* d, const float* vp, vo
 template <typename T, bool XACC>
 static int launch_synth_x(const void* x, const float* d, const float* vp, void* out, int B, int P, int K,
                           float delta_clamp, int pixel_clamp, hipStream_t st) {
-    const bool vec = (P % 4 == 0) && (((uintptr_t)out | (uintptr_t)x) % 16 == 0);
+    // FAST = vector-aligned rows, and a 32-row block addressable with 32-bit byte offsets (buffer instructions)
+    const bool vec = (P % 4 == 0) && (((uintptr_t)out | (uintptr_t)x | (uintptr_t)d) % 16 == 0) && (P <= (1 << 23));
     const int ntiles = (P + SYNTH_TILE - 1) / SYNTH_TILE;
     const int nfast = vec ? P / SYNTH_TILE : 0;
     int rc = launch_synth_range<T, XACC, true>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, 0, nfast, st);

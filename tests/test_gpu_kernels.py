@@ -224,6 +224,30 @@ def test_full_size_configs(b, k, dt):
     assert torch.equal(gd, gd2) and torch.equal(gvb, gvb2)
 
 
+@pytest.mark.parametrize("b,k,dt", [(70, 50, torch.bfloat16), (70, 50, torch.float32), (96, 128, torch.float32),
+                                    (33, 128, torch.bfloat16), (1, 7, torch.float32)])
+def test_synth_guard_rows_and_store_hazard(b, k, dt):
+    """Full image size, ragged batch: (1) rows >= B of the output allocation stay untouched (the aligned interior
+    clips rows through the buffer descriptor's num_records), (2) repeated launches agree bit for bit with each other
+    and with fp64 — the fp32 path once lost rows to a >64-bit store-data hazard that only showed under load."""
+    gen = torch.Generator().manual_seed(7 * b + k)
+    P = 150528
+    d = (-1 + 2 * torch.rand(1, 1, P, k, generator=gen)).to(DEV)
+    v = (torch.randn(b, k, generator=gen) * 0.02).to(DEV)
+    x = torch.rand(b, 1, 1, P, generator=gen).to(DEV).to(dt)
+    buf = torch.full((b + 40, 1, 1, P), 7.0, device=DEV, dtype=dt)
+    vp = ops().pack_codes(v, None, b)
+    dq, vq = (d.bfloat16().double(), v.bfloat16().double()) if dt == torch.bfloat16 else (d.double(), v.double())
+    ref = (x.double().reshape(b, -1) + vq @ dq.reshape(-1, k).t()).reshape(x.shape)
+    first = None
+    for _ in range(4):
+        out = ops().synth(x, d, vp, b, out=buf[:b])
+        assert bool((buf[b:] == 7.0).all()), "rows beyond the batch were written"
+        close(out.double(), ref.to(dt).double(), 2 ** -7 if dt == torch.bfloat16 else 2e-5)
+        first = out.clone() if first is None else first
+        assert torch.equal(first, out)
+
+
 # ----------------------------------------------------------------------------- optimiser
 def test_adamw_steps_golden():
     """T steps of {AdamW(d,v); l1-ball(v); clamp(d)} against the reference's torch.optim.AdamW trajectory (G6)."""
