@@ -18,6 +18,15 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return __builtin_bit_cast(unsigned short, h);
 }
 
+// two floats -> one dword of packed bf16 (lo = a, hi = b), round to nearest even: ONE v_cvt_pk_bf16_f32 on gfx950
+// (converting element-wise and OR-ing the halves costs six VALU instructions per pair)
+typedef float adil_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 adil_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
+    const adil_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, adil_bf16x2));
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static __device__ __forceinline__ float load(const float* p, size_t i) { return p[i]; }

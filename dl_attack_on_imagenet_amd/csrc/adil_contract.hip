@@ -56,10 +56,10 @@ template <> struct Mma<bf16_t> {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     }
     static __device__ __forceinline__ Frag from8(const float (&f)[8]) {
-        Frag r;
+        u32x4 t;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = (__bf16)f[j];
-        return r;
+        for (int j = 0; j < 4; ++j) t[j] = pack2_bf16(f[2 * j], f[2 * j + 1]);
+        return __builtin_bit_cast(Frag, t);
     }
     static __device__ __forceinline__ Elem to_elem(float x) { return f32_to_bf16(x); }
     static __device__ __forceinline__ void touch(Frag& f) {
@@ -88,8 +88,8 @@ template <> struct PixVec<bf16_t, 4> {
     }
     static __device__ __forceinline__ void store(bf16_t* p, const float (&o)[4]) {
         uint2 t;
-        t.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
-        t.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+        t.x = pack2_bf16(o[0], o[1]);
+        t.y = pack2_bf16(o[2], o[3]);
         *reinterpret_cast<uint2*>(p) = t;
     }
 };
@@ -178,8 +178,8 @@ template <> struct BufPx<bf16_t> {
     }
     static __device__ __forceinline__ void store(buf_rsrc r, int voff, int soff, const float (&o)[4]) {
         Raw t;
-        t[0] = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
-        t[1] = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+        t[0] = pack2_bf16(o[0], o[1]);
+        t[1] = pack2_bf16(o[2], o[3]);
         __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
     }
 };
@@ -206,6 +206,23 @@ __device__ __forceinline__ typename Mma<T>::Frag frag_from_f32x8(const float* p)
     const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
     const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     return Mma<T>::from8(f);
+}
+
+// N (2 or 4) consecutive fp32 values -> LDS as ONE store of the staged element type (address N-element aligned)
+template <typename E, int N> __device__ __forceinline__ void lds_put(E* p, const float (&f)[N]);
+template <> __device__ __forceinline__ void lds_put<float, 4>(float* p, const float (&f)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+}
+template <> __device__ __forceinline__ void lds_put<float, 2>(float* p, const float (&f)[2]) {
+    *reinterpret_cast<float2*>(p) = make_float2(f[0], f[1]);
+}
+template <> __device__ __forceinline__ void lds_put<bf16_t, 4>(bf16_t* p, const float (&f)[4]) {
+    u32x2 t;
+    t[0] = pack2_bf16(f[0], f[1]); t[1] = pack2_bf16(f[2], f[3]);
+    *reinterpret_cast<u32x2*>(p) = t;
+}
+template <> __device__ __forceinline__ void lds_put<bf16_t, 2>(bf16_t* p, const float (&f)[2]) {
+    *reinterpret_cast<unsigned*>(p) = pack2_bf16(f[0], f[1]);
 }
 
 // Workgroup barrier for LDS hand-offs that leaves global loads in flight.  __syncthreads() carries a workgroup-scope
@@ -339,6 +356,11 @@ __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const f
         const int rows = B - b0 < 32 ? B - b0 : 32;
         const buf_rsrc rx = block_rsrc(x ? x + (size_t)b0 * P : nullptr, x ? (unsigned)rows * rowb : 0u);
         const buf_rsrc ro = block_rsrc(out + (size_t)b0 * P, (unsigned)rows * rowb);
+        typename BP::Raw xr[16];
+        if (XACC) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) xr[reg] = BP::load(rx, voff, (int)((unsigned)c_row(reg, 0) * rowb));
+        }
         const float* arow = vp + (size_t)(b0 + c) * Kp + 8 * h;
         float4 araw[SYNTH_HOIST][2];
 #pragma unroll
@@ -347,14 +369,16 @@ __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const f
             araw[g][0] = *reinterpret_cast<const float4*>(ap);
             araw[g][1] = *reinterpret_cast<const float4*>(ap + 4);
         }
-        typename BP::Raw xr[16];
-        if (XACC) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) xr[reg] = BP::load(rx, voff, (int)((unsigned)c_row(reg, 0) * rowb));
-        }
+        // All loads of the block are in flight before anything is consumed.  Left alone, hipcc sinks the code loads
+        // (and their conversion) into the `g < NG` blocks next to their MFMAs: one exposed L2 round trip per k-group.
+        // The opaque uses below pin them here (the x loads were issued first, so nothing waits longer than it must).
+        __builtin_amdgcn_sched_barrier(0);
         Frag a[SYNTH_HOIST];
 #pragma unroll
         for (int g = 0; g < SYNTH_HOIST; ++g) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                asm volatile("" : "+v"(araw[g][u].x), "+v"(araw[g][u].y), "+v"(araw[g][u].z), "+v"(araw[g][u].w));
             const float f[8] = {araw[g][0].x, araw[g][0].y, araw[g][0].z, araw[g][0].w,
                                 araw[g][1].x, araw[g][1].y, araw[g][1].z, araw[g][1].w};
             a[g] = M::from8(f);
@@ -397,7 +421,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
     E* sd = reinterpret_cast<E*>(smem_raw);
     const int Ks = Kp + M::PAD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+#ifdef SYNTH_XCD_REMAP
+    // workgroups are dealt round-robin to the 8 XCDs: give each XCD one contiguous range of tiles
+    int bid = blockIdx.x;
+    {
+        const int n = gridDim.x, per = n >> 3, full = per << 3;
+        if (bid < full) bid = (bid & 7) * per + (bid >> 3);
+    }
+    const int p0 = (tile0 + bid) * SYNTH_TILE;
+#else
     const int p0 = (tile0 + blockIdx.x) * SYNTH_TILE;
+#endif
     if constexpr (FAST) {
         // D slice -> LDS.  The slice (128 pixels x K atoms) is one contiguous, 16-byte aligned run of 32*K float4:
         // every thread issues up to 8 independent 16-byte loads before the first conversion, so the fill costs ONE
@@ -421,10 +455,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                     int r = (int)(((float)i + 0.5f) * rk);           // i / K, exact: |error| << 0.5 / K for i < 2^14
                     int k = i - r * K;
                     const float e4[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
+                    if ((K & 3) == 0) {                              // uniform: the quad stays inside one row
+                        lds_put<E, 4>(sd + ((r & 3) * 32 + (r >> 2)) * Ks + k, e4);
+                    } else if ((K & 1) == 0) {                       // pairs stay inside one row
+                        const float lo[2] = {e4[0], e4[1]}, hi[2] = {e4[2], e4[3]};
+                        lds_put<E, 2>(sd + ((r & 3) * 32 + (r >> 2)) * Ks + k, lo);
+                        k += 2;
+                        if (k == K) { k = 0; ++r; }
+                        lds_put<E, 2>(sd + ((r & 3) * 32 + (r >> 2)) * Ks + k, hi);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        sd[((r & 3) * 32 + (r >> 2)) * Ks + k] = M::to_elem(e4[e]);
-                        if (++k == K) { k = 0; ++r; }
+                        for (int e = 0; e < 4; ++e) {
+                            sd[((r & 3) * 32 + (r >> 2)) * Ks + k] = M::to_elem(e4[e]);
+                            if (++k == K) { k = 0; ++r; }
+                        }
                     }
                 }
             }

@@ -536,7 +536,7 @@ template <> struct ActVec<bf16_t, 8> {
     static __device__ __forceinline__ void store(bf16_t* p, size_t i, const float (&o)[8]) {
         unsigned w[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = (unsigned)f32_to_bf16(o[2 * q]) | ((unsigned)f32_to_bf16(o[2 * q + 1]) << 16);
+        for (int q = 0; q < 4; ++q) w[q] = pack2_bf16(o[2 * q], o[2 * q + 1]);
         *reinterpret_cast<uint4*>(p + i) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
