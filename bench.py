@@ -43,6 +43,9 @@ def parse_args():
     p.add_argument("--fuse-bn-act", type=int, default=1,
                    help="ResNets: run eval-BatchNorm + residual + ReLU as one epilogue kernel per convolution "
                         "(zoo.FusedResNet; conv weights untouched; supersedes --fold-bn)")
+    p.add_argument("--fuse-stem", type=int, default=1,
+                   help="ResNets with --fuse-bn-act, bf16: Normalize + conv1 + bn1 + ReLU + maxpool (forward and input "
+                        "gradient) as the hand-written stem kernels (csrc/adil_stem.hip)")
     p.add_argument("--pad-cin", type=int, default=8,
                    help="zero-pad the first conv's 3 input channels to this width (0 = off); see zoo.ChannelPaddedConv")
     p.add_argument("--cache-labels", type=int, default=0,
@@ -140,7 +143,9 @@ def main():
 
     model = zoo.build_classifier(args.model, seed=0, device=dev, dtype=sdtype, channels_last=bool(args.channels_last),
                                  fold_bn=bool(args.fold_bn), pad_input_channels=args.pad_cin,
-                                 fuse_bn_act=bool(args.fuse_bn_act))
+                                 fuse_bn_act=bool(args.fuse_bn_act),
+                                 fuse_stem=bool(args.fuse_stem and args.fuse_bn_act and args.dtype == "bf16"
+                                                and zoo.canonical_name(args.model).startswith("resnet")))
     gen = torch.Generator().manual_seed(1000 + rank)                 # each rank owns different images (weak scaling)
     x = torch.rand(B, *shape, generator=gen).to(dev).to(sdtype).contiguous()
     gd0 = torch.Generator().manual_seed(7)                           # the same D0 on every rank
@@ -204,7 +209,7 @@ def main():
                                f"{'cached' if args.cache_labels else 'recomputed'} pseudo-labels (2 fwd + 1 bwd)",
                    "classifier": f"random-init {args.model}, frozen, eval; channels_last={args.channels_last}, "
                                  f"bn_act_epilogue_fused={args.fuse_bn_act}, bn_folded={args.fold_bn}, "
-                                 f"first_conv_cin_padded_to={args.pad_cin}",
+                                 f"first_conv_cin_padded_to={args.pad_cin}, stem_kernels={args.fuse_stem}",
                    "global_batch": world * B, "atoms": K, "inner_iters": args.steps,
                    "parallelism": f"dp{world}: images+codes sharded, D replicated, 1 all-reduce(grad_d)/step",
                    "train_fooling_rate_last_step": fool_rate},

@@ -38,6 +38,12 @@ SIGNATURES = {
                                     c_void_p]),
     "adil_affine_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int,
                                     c_void_p]),
+    "adil_stem_conv_fwd": (c_int, [c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_float, c_float, c_float,
+                                   c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "adil_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "adil_stem_pool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "adil_stem_conv_bwd": (c_int, [c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_void_p]),
 }
 
 ABI_VERSION = 1

@@ -366,6 +366,66 @@ def affine_act(x: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = 
 
 
 # --------------------------------------------------------------------------- #
+def pack_stem_weights(weight: Tensor) -> Tuple[Tensor, Tensor]:
+    """(64,3,7,7) conv weight -> the two bf16 layouts of include/adil_hip.h: w_fwd [64][7][8][4], w_bwd [4][49][64]."""
+    if tuple(weight.shape) != (64, 3, 7, 7):
+        raise ValueError(f"stem kernels are written for a (64,3,7,7) convolution, got {tuple(weight.shape)}")
+    w = weight.detach().float()
+    wf = torch.zeros(64, 7, 8, 4, dtype=torch.float32, device=w.device)
+    wf[:, :, :7, :3] = w.permute(0, 2, 3, 1)                       # [co][kh][kw][ci]
+    wb = torch.zeros(4, 49, 64, dtype=torch.float32, device=w.device)
+    wb[:3] = w.permute(1, 2, 3, 0).reshape(3, 49, 64)               # [ci][kh*7+kw][co]
+    # 2-D on purpose: nn.Module.to(memory_format=channels_last) re-strides every 4-D buffer
+    return wf.to(torch.bfloat16).reshape(64, 224).contiguous(), wb.to(torch.bfloat16).reshape(4, 49 * 64).contiguous()
+
+
+class StemFunction(torch.autograd.Function):
+    """Normalize -> conv7x7/2 -> BatchNorm(eval) -> ReLU -> maxpool3x3/2 of a frozen ResNet as four HIP kernels
+    (csrc/adil_stem.hip), forward and input gradient.  x: (B,3,H,W) fp32/bf16 contiguous; returns the pooled
+    activation as a (B,64,H/4,W/4) bf16 tensor in channels_last storage."""
+
+    @staticmethod
+    def forward(ctx, x, w_fwd, w_bwd, scale, shift, mean, inv_std):
+        lib = _lib.load()
+        x = _dev(x.contiguous(), "x")
+        _dev(w_fwd, "w_fwd", torch.bfloat16), _dev(w_bwd, "w_bwd", torch.bfloat16)
+        _dev(scale, "scale", torch.float32), _dev(shift, "shift", torch.float32)
+        b, _, h, w = x.shape
+        if h % 2 or w % 2:
+            raise ValueError("stem kernels need even H and W")
+        oh, ow = h // 2, w // 2
+        ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
+        y1 = torch.empty((b, oh, ow, 64), dtype=torch.bfloat16, device=x.device)
+        _lib.check(lib.adil_stem_conv_fwd(_ptr(x), stream_dtype_code(x.dtype), _ptr(w_fwd), *mean, *inv_std, _ptr(scale),
+                                          _ptr(shift), _ptr(y1), b, h, w, _stream()), "adil_stem_conv_fwd")
+        p = torch.empty((b, ph, pw, 64), dtype=torch.bfloat16, device=x.device)
+        idx = torch.empty((b, ph, pw, 64), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.adil_maxpool_fwd(_ptr(y1), _ptr(p), _ptr(idx), b, oh, ow, 64, _stream()), "adil_maxpool_fwd")
+        ctx.save_for_backward(p, idx, w_bwd, scale)
+        ctx.meta = (b, h, w, x.dtype, tuple(inv_std))
+        return p.permute(0, 3, 1, 2)                                 # logical NCHW, channels_last storage
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        p, idx, w_bwd, scale = ctx.saved_tensors
+        b, h, w, xdtype, inv_std = ctx.meta
+        oh, ow = h // 2, w // 2
+        g = g.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()   # NHWC (a no-op for channels_last gradients)
+        gy = torch.empty((b, oh, ow, 64), dtype=torch.bfloat16, device=g.device)
+        _lib.check(lib.adil_stem_pool_bwd(_ptr(g), _ptr(idx), _ptr(p), _ptr(scale), _ptr(gy), b, oh, ow, 64, _stream()),
+                   "adil_stem_pool_bwd")
+        gx = torch.empty((b, 3, h, w), dtype=xdtype, device=g.device)
+        _lib.check(lib.adil_stem_conv_bwd(_ptr(gy), _ptr(w_bwd), *inv_std, _ptr(gx), stream_dtype_code(xdtype), b, h, w,
+                                          _stream()), "adil_stem_conv_bwd")
+        return gx, None, None, None, None, None, None
+
+
+def resnet_stem(x: Tensor, w_fwd: Tensor, w_bwd: Tensor, scale: Tensor, shift: Tensor, mean, inv_std) -> Tensor:
+    return StemFunction.apply(x, w_fwd, w_bwd, scale, shift, tuple(float(m) for m in mean), tuple(float(s) for s in inv_std))
+
+
+# --------------------------------------------------------------------------- #
 class DictSynthFunction(torch.autograd.Function):
     """x + D v[index] as a differentiable op (the tensordot of adil.py:25 and its autograd backward).
     grad wrt v is dense (N,K) with zero rows outside `index`, exactly what autograd produces."""

@@ -425,30 +425,63 @@ class _FusedResBlock(nn.Module):
         return self.c2(out, res=idt)
 
 
+class _FusedStem(nn.Module):
+    """Normalize -> conv1 7x7/2 -> bn1(eval) -> ReLU -> maxpool as the hand-written stem kernels (`ops.resnet_stem`):
+    consumes the attack's (B,3,H,W) fp32/bf16 tensor directly and returns bf16 channels_last activations; its
+    backward produces dLoss/dx in the layout `adil_grad` reads.  bf16 networks on the GPU only."""
+
+    def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, mean, std):
+        super().__init__()
+        from . import ops
+        if conv.bias is not None or conv.stride != (2, 2) or conv.padding != (3, 3):
+            raise ValueError("stem kernels implement the torchvision ResNet conv1 (7x7, stride 2, padding 3, no bias)")
+        w_fwd, w_bwd = ops.pack_stem_weights(conv.weight)
+        scale, shift = _bn_affine(bn)
+        self.register_buffer('w_fwd', w_fwd)
+        self.register_buffer('w_bwd', w_bwd)
+        self.register_buffer('scale', scale)
+        self.register_buffer('shift', shift)
+        self.mean = [float(m) for m in mean]
+        self.inv_std = [1.0 / float(s) for s in std]
+
+    def forward(self, x):
+        from . import ops
+        return ops.resnet_stem(x, self.w_fwd, self.w_bwd, self.scale, self.shift, self.mean, self.inv_std)
+
+
 class FusedResNet(nn.Module):
     """A frozen ResNet whose BatchNorm(eval) / residual add / ReLU run as ONE elementwise kernel per convolution
     (`ops.affine_act`, forward and input-gradient backward) instead of 2-3 separate PyTorch kernels.  Convolution
-    weights are untouched; the function is the original network's (up to one rounding per activation).  GPU only."""
+    weights are untouched; the function is the original network's (up to one rounding per activation).  GPU only.
+    With `normalize=(mean, std)` the input normalisation and the whole first stage run in the stem kernels."""
 
-    def __init__(self, net: ResNet):
+    def __init__(self, net: ResNet, normalize=None):
         super().__init__()
-        self.stem = _ConvAffine(net.conv1, net.bn1, True)
-        self.maxpool = net.maxpool
+        if normalize is not None:
+            self.fstem = _FusedStem(net.conv1, net.bn1, *normalize)
+            self.stem, self.maxpool = None, None
+        else:
+            self.fstem = None
+            self.stem = _ConvAffine(net.conv1, net.bn1, True)
+            self.maxpool = net.maxpool
         self.layers = nn.Sequential(*[_FusedResBlock(b) for layer in (net.layer1, net.layer2, net.layer3, net.layer4)
                                       for b in layer])
         self.avgpool, self.fc = net.avgpool, net.fc
 
     def forward(self, x):
-        x = self.layers(self.maxpool(self.stem(x)))
+        x = self.fstem(x) if self.fstem is not None else self.maxpool(self.stem(x))
+        x = self.layers(x)
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 
 def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights: Optional[str] = None,
                      device=None, dtype: torch.dtype = torch.float32, channels_last: bool = False,
-                     fold_bn: bool = False, pad_input_channels: int = 0, fuse_bn_act: bool = False) -> nn.Module:
+                     fold_bn: bool = False, pad_input_channels: int = 0, fuse_bn_act: bool = False,
+                     fuse_stem: bool = False) -> nn.Module:
     """Sequential(Normalize, net), eval mode, parameters frozen — the object both CLIs hand to ADIL.
-    fold_bn / pad_input_channels / fuse_bn_act apply the function-preserving rewrites above (off by default);
-    fuse_bn_act (ResNets, GPU only) supersedes fold_bn."""
+    fold_bn / pad_input_channels / fuse_bn_act / fuse_stem apply the function-preserving rewrites above (off by
+    default); fuse_bn_act (ResNets, GPU only) supersedes fold_bn; fuse_stem (with fuse_bn_act, bf16 only) moves the
+    normalisation and the first stage into the stem kernels (the Sequential then holds the network alone)."""
     key = canonical_name(name)
     with torch.random.fork_rng(devices=[]):
         torch.manual_seed(seed)
@@ -456,11 +489,16 @@ def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights:
     if weights is not None:
         net.load_state_dict(torch.load(weights, map_location='cpu'))
     net.eval()
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    stem_fused = False
     if fuse_bn_act and isinstance(net, ResNet):
-        net = FusedResNet(net)
+        stem_fused = bool(fuse_stem)
+        if stem_fused and dtype != torch.bfloat16:
+            raise ValueError("fuse_stem needs a bfloat16 network (the stem kernels produce bf16 activations)")
+        net = FusedResNet(net, normalize=(mean, std) if stem_fused else None)
     elif fold_bn:
         fold_batchnorm_(net)
-    model = nn.Sequential(Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225]), net)
+    model = nn.Sequential(net) if stem_fused else nn.Sequential(Normalize(mean=mean, std=std), net)
     model.eval()
     for p in model.parameters():
         p.requires_grad_(False)
@@ -468,8 +506,8 @@ def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights:
     if channels_last:
         model = model.to(memory_format=torch.channels_last)
     for m in model.modules():                                # epilogue tables stay fp32 whatever the activation dtype
-        if isinstance(m, _ConvAffine):
+        if isinstance(m, (_ConvAffine, _FusedStem)):
             m.scale, m.shift = m.scale.float(), m.shift.float()
-    if pad_input_channels:
+    if pad_input_channels and not stem_fused:
         pad_first_conv_(net, pad_input_channels)
     return model

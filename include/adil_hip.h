@@ -142,6 +142,26 @@ int adil_affine_act_fwd(const void* x, const void* res, const float* scale, cons
 int adil_affine_act_bwd(const void* g, const void* y, const float* scale, void* gx, void* gres, size_t n, int C,
                         int inner, int relu, int dtype, void* stream);
 
+/* Frozen-classifier stem, the stage on either side of the hot path for the torchvision ResNets the reference attacks
+ * (demo_dL_attack.py:41-59; NOT part of the ADiL maths): Normalize -> conv 7x7/2 (3->64) -> BatchNorm(eval) -> ReLU ->
+ * maxpool 3x3/2, forward and input gradient, on the attack's own layouts (x_adv / dLoss/dx_adv are B x 3 x H x W in the
+ * stream dtype; activations are NHWC bf16).  H and W even.  Weights are pre-packed bf16:
+ *     w_fwd [64][7][8][4]  = w[co][ci][kh][kw] at [co][kh][kw][ci], zero for kw = 7 / ci = 3
+ *     w_bwd [4][49][64]    = w[co][ci][kh][kw] at [ci][kh*7+kw][co], zero for ci = 3
+ *   adil_stem_conv_fwd : y1 = relu((conv((x - mean) * inv_std)) * scale[co] + shift[co]),  y1 is B x H/2 x W/2 x 64
+ *   adil_maxpool_fwd   : p = maxpool3x3/2/pad1(y) (B x OH x OW x C -> B x PH x PW x C, PH = (OH-1)/2+1), idx = position
+ *                        kh*3+kw of the first maximum (torch.nn.functional.max_pool2d's rule); C % 8 == 0
+ *   adil_stem_pool_bwd : gy = route(g; idx) * [p > 0] * scale[c]   (maxpool + ReLU + BatchNorm backward, B x OH x OW x C)
+ *   adil_stem_conv_bwd : gx = inv_std[ci] * conv7x7/2 input gradient of gy   (B x 3 x H x W, gx_dtype) */
+int adil_stem_conv_fwd(const void* x, int x_dtype, const void* w_fwd, float mean0, float mean1, float mean2, float inv_std0,
+                       float inv_std1, float inv_std2, const float* scale, const float* shift, void* y, int B, int H, int W,
+                       void* stream);
+int adil_maxpool_fwd(const void* y, void* p, uint8_t* idx, int B, int OH, int OW, int C, void* stream);
+int adil_stem_pool_bwd(const void* g, const uint8_t* idx, const void* p, const float* scale, void* gy, int B, int OH, int OW,
+                       int C, void* stream);
+int adil_stem_conv_bwd(const void* gy, const void* w_bwd, float inv_std0, float inv_std1, float inv_std2, void* gx,
+                       int gx_dtype, int B, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,123 @@
+"""GPU parity of the hand-written ResNet stem kernels (csrc/adil_stem.hip) against plain PyTorch fp32 references of
+the same ops on the same (bf16-rounded) operands.  These kernels sit on either side of the ADiL hot path (they
+consume x_adv and produce dLoss/dx_adv); tolerances are bf16 output rounding (2^-8 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+
+def ops():
+    from dl_attack_on_imagenet_amd import ops as o
+    return o
+
+
+def _stem_params(seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    w = (torch.randn(64, 3, 7, 7, generator=gen) * 0.05).bfloat16().float()
+    scale = (0.5 + torch.rand(64, generator=gen)).float()
+    shift = (torch.randn(64, generator=gen) * 0.2).float()
+    return w, scale, shift
+
+
+def _ref_conv_stage(x, w, scale, shift):
+    """y1 = relu(bn(conv(normalize(x)))) in fp32 on the bf16-rounded normalised input, rounded to bf16 at the end."""
+    mean = torch.tensor(MEAN, device=x.device).reshape(1, 3, 1, 1)
+    inv = (1.0 / torch.tensor(STD, device=x.device)).reshape(1, 3, 1, 1)
+    xn = ((x.float() - mean) * inv).bfloat16().float()
+    y = F.conv2d(xn, w, stride=2, padding=3)
+    return torch.relu(y * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1))
+
+
+@pytest.mark.parametrize("b,h,w_", [(2, 64, 64), (3, 32, 96), (1, 40, 24), (2, 224, 224)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_stem_conv_fwd(b, h, w_, dt):
+    o = ops()
+    lib = __import__("dl_attack_on_imagenet_amd._lib", fromlist=["x"])
+    w, scale, shift = _stem_params()
+    gen = torch.Generator().manual_seed(b * h + w_)
+    x = torch.rand(b, 3, h, w_, generator=gen).to(DEV).to(dt)
+    w, scale, shift = w.to(DEV), scale.to(DEV), shift.to(DEV)     # keep the device copies alive across the launch
+    wf, wb = o.pack_stem_weights(w)
+    y1 = torch.empty(b, h // 2, w_ // 2, 64, dtype=torch.bfloat16, device=DEV)
+    rc = lib.load().adil_stem_conv_fwd(o._ptr(x), o.stream_dtype_code(dt), o._ptr(wf), *MEAN, *[1.0 / s for s in STD],
+                                       o._ptr(scale), o._ptr(shift), o._ptr(y1), b, h, w_, o._stream())
+    assert rc == 0
+    ref = _ref_conv_stage(x, w, scale, shift).permute(0, 2, 3, 1)
+    err = (y1.float() - ref).abs()
+    tol = 2 ** -7 * ref.abs() + 2e-2          # bf16 output rounding + fp32 accumulation-order differences
+    assert bool((err <= tol).all()), float((err - tol).max())
+    assert float(err.mean()) < 2e-3
+
+
+@pytest.mark.parametrize("b,oh,ow,c", [(2, 32, 32, 64), (3, 17, 23, 64), (1, 112, 112, 64), (2, 8, 6, 16)])
+def test_maxpool_fwd_and_fused_bwd(b, oh, ow, c):
+    """maxpool values bit-exact against torch; routing (first maximum, ties included) + ReLU mask + BN scale against
+    torch autograd on the same tensor."""
+    o = ops()
+    lib = __import__("dl_attack_on_imagenet_amd._lib", fromlist=["x"]).load()
+    gen = torch.Generator().manual_seed(oh * ow)
+    y1 = torch.relu(torch.randn(b, oh, ow, c, generator=gen)).bfloat16().to(DEV)      # NHWC, many zeros, many ties
+    ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
+    p = torch.empty(b, ph, pw, c, dtype=torch.bfloat16, device=DEV)
+    idx = torch.empty(b, ph, pw, c, dtype=torch.uint8, device=DEV)
+    assert lib.adil_maxpool_fwd(o._ptr(y1), o._ptr(p), o._ptr(idx), b, oh, ow, c, o._stream()) == 0
+    t = y1.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    pref = F.max_pool2d(t, 3, 2, 1)
+    assert torch.equal(p.float().permute(0, 3, 1, 2), pref.detach())
+    g = torch.randn(b, ph, pw, c, generator=gen).bfloat16().to(DEV)
+    scale = (0.5 + torch.rand(c, generator=gen)).to(DEV)
+    gy = torch.empty(b, oh, ow, c, dtype=torch.bfloat16, device=DEV)
+    assert lib.adil_stem_pool_bwd(o._ptr(g), o._ptr(idx), o._ptr(p), o._ptr(scale), o._ptr(gy), b, oh, ow, c, o._stream()) == 0
+    pref.backward(g.float().permute(0, 3, 1, 2))
+    ref = (t.grad * (t.detach() > 0) * scale.reshape(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    err = (gy.float() - ref).abs()
+    assert bool((err <= 2 ** -7 * ref.abs() + 1e-6).all()), float(err.max())
+
+
+@pytest.mark.parametrize("b,h,w_", [(2, 64, 64), (1, 32, 96), (2, 40, 24), (1, 224, 224)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_stem_conv_bwd(b, h, w_, dt):
+    o = ops()
+    lib = __import__("dl_attack_on_imagenet_amd._lib", fromlist=["x"]).load()
+    w, _, _ = _stem_params(1)
+    gen = torch.Generator().manual_seed(h + 3 * w_)
+    gy = (torch.randn(b, h // 2, w_ // 2, 64, generator=gen) * 0.1).bfloat16().to(DEV)
+    w = w.to(DEV)
+    wf, wb = o.pack_stem_weights(w)
+    gx = torch.empty(b, 3, h, w_, dtype=dt, device=DEV)
+    inv = [1.0 / s for s in STD]
+    assert lib.adil_stem_conv_bwd(o._ptr(gy), o._ptr(wb), *inv, o._ptr(gx), o.stream_dtype_code(dt), b, h, w_, o._stream()) == 0
+    xin = torch.zeros(b, 3, h, w_, device=DEV, requires_grad=True)
+    F.conv2d(xin, w, stride=2, padding=3).backward(gy.float().permute(0, 3, 1, 2))
+    ref = xin.grad * torch.tensor(inv, device=DEV).reshape(1, 3, 1, 1)
+    err = (gx.float() - ref).abs()
+    tol = (2 ** -7 if dt == torch.bfloat16 else 1e-5) * ref.abs() + 1e-3
+    assert bool((err <= tol).all()), float((err - tol).max())
+
+
+def test_fused_stem_resnet_matches_unfused():
+    """ResNet-18 with the stem kernels: against the fp32 network (same weights) its logits and input gradient are as
+    accurate as the bf16 conv + epilogue path's (both differ from fp32 only by bf16 rounding of activations)."""
+    from dl_attack_on_imagenet_amd import zoo
+    ref = zoo.build_classifier("resnet18", num_classes=10, seed=3, device=DEV, dtype=torch.float32)
+    kw = dict(num_classes=10, seed=3, device=DEV, dtype=torch.bfloat16, channels_last=True, fuse_bn_act=True)
+    m0 = zoo.build_classifier("resnet18", **kw)
+    m1 = zoo.build_classifier("resnet18", fuse_stem=True, **kw)
+    gen = torch.Generator().manual_seed(0)
+    x = torch.rand(8, 3, 64, 64, generator=gen).to(DEV).bfloat16()
+    xr, x0, x1 = (x.float().requires_grad_(True), x.clone().requires_grad_(True), x.clone().requires_grad_(True))
+    lr, l0, l1 = ref(xr), m0(x0).float(), m1(x1).float()
+    e0, e1 = float((l0 - lr).abs().mean()), float((l1 - lr).abs().mean())
+    assert e1 <= 1.5 * e0 + 1e-3, (e0, e1)
+    (gr,) = torch.autograd.grad(lr.square().sum(), xr)
+    (g0,) = torch.autograd.grad(l0.square().sum(), x0)
+    (g1,) = torch.autograd.grad(l1.square().sum(), x1)
+    assert g1.dtype == x.dtype and g1.shape == x.shape
+    cos = lambda a, b: float(F.cosine_similarity(a.float().flatten(), b.float().flatten(), dim=0))
+    c0, c1 = cos(g0, gr), cos(g1, gr)
+    assert c1 >= c0 - 0.02, (c0, c1)
