@@ -399,10 +399,23 @@ class _ConvAffine(nn.Module):
         scale, shift = _bn_affine(bn)
         self.register_buffer('scale', scale)
         self.register_buffer('shift', shift)
+        # a 1x1 / stride-1 convolution of a channels_last tensor IS a row-major GEMM (B*H*W x Cin) @ (Cin x Cout)
+        self.pointwise = (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+                          and conv.groups == 1 and conv.bias is None)
+
+    def _conv(self, x):
+        if self.pointwise and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last):
+            # hipBLASLt instead of MIOpen: no zero-fill launch in front of the kernel (MIOpen's implicit-GEMM solvers
+            # clear their output first: 6 ms of a 55 ms step at B=512) and a faster kernel on most ResNet-50 shapes
+            b, cin, h, w = x.shape
+            wt = self.conv.weight.reshape(self.conv.out_channels, cin).t()            # (Cin, Cout) view
+            y2 = torch.mm(x.permute(0, 2, 3, 1).reshape(b * h * w, cin), wt)
+            return y2.reshape(b, h, w, -1).permute(0, 3, 1, 2)                         # channels_last storage
+        return self.conv(x)
 
     def forward(self, x, res=None):
         from . import ops
-        return ops.affine_act(self.conv(x), self.scale.float(), self.shift.float(), res=res, relu=self.relu)
+        return ops.affine_act(self._conv(x), self.scale.float(), self.shift.float(), res=res, relu=self.relu)
 
 
 class _FusedResBlock(nn.Module):
