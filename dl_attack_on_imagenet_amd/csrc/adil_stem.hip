@@ -398,3 +398,163 @@ extern "C" int adil_stem_conv_bwd(const void* gy, const void* w_bwd, float inv_s
     ADIL_CHECK_LAUNCH();
     return 0;
 }
+
+// =========================================================================================================== //
+// Pointwise (1x1, stride 1) convolution of the frozen ResNet with its eval-BatchNorm / residual / ReLU epilogue
+// in ONE kernel.  On channels_last storage the convolution is the row-major GEMM
+//     Y[M][N] = act( (X[M][K] . W[N][K]^T) * scale[n] + shift[n] (+ R[M][N]) ),   M = B*H*W, K = Cin, N = Cout
+// and at ResNet-50 / B = 512 it is HBM-bound (K <= 2048, activations of 0.1 - 0.8 GB): what matters is that every
+// activation crosses HBM once.  A library GEMM + a separate epilogue kernel writes and re-reads the pre-activation
+// tensor (the epilogue passes were 10.5 ms of a 51 ms step); here the epilogue runs on the accumulators.
+//   Workgroup = 128 pixels x BN channels (BN = 128 or 64), K in chunks of 64 through double-buffered LDS.
+//   MFMA roles as in the stem: A = W (rows = channels -> accumulator registers), B = X (columns = pixels -> lanes),
+//   so a lane owns 4 consecutive channels of one pixel per register quad (8-byte residual loads); the finished tile
+//   goes through a per-wave LDS transpose to 16-byte NHWC stores.
+// =========================================================================================================== //
+namespace {
+
+#define PW_BM 128
+#define PW_BK 64
+#define PW_LS (PW_BK + 8)              // LDS row stride (elements): 144 B = 9 x 16 B
+
+template <int BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void pw_conv_fwd_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ wgt, const float* __restrict__ scale,
+    const float* __restrict__ shift, const bf16_t* __restrict__ res, bf16_t* __restrict__ y, int M, int K, int N,
+    int relu, int MT, int NT) {
+    constexpr int CT = BN / 32;                          // channel tiles per wave
+    constexpr int XCH = PW_BM * PW_BK / 8 / 256;         // 16-byte chunks of the X tile per thread (4)
+    constexpr int WCH = BN * PW_BK / 8 / 256;            // ... of the W tile (4 or 2)
+    constexpr int OS = BN + 8;                           // transposed-output pixel stride (elements)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sx = reinterpret_cast<bf16_t*>(smem_raw);    // [2][128][PW_LS]
+    bf16_t* sw = sx + 2 * PW_BM * PW_LS;                 // [2][BN][PW_LS]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    // workgroups are dealt round-robin to the 8 XCDs: consecutive workgroups of ONE XCD share the pixel tile, so the
+    // NT reads of an X tile meet in that XCD's L2
+    int mt, nt;
+    if ((MT & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        nt = j % NT;
+        mt = (j / NT) * 8 + xcd;
+    } else {
+        nt = blockIdx.x % NT;
+        mt = blockIdx.x / NT;
+    }
+    const int m0 = mt * PW_BM, n0 = nt * BN;
+    const int nk = K / PW_BK;
+
+    u32x4 xr[XCH], wr[WCH];
+    auto load_tiles = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            const int m = m0 + row;
+            xr[i] = *reinterpret_cast<const u32x4*>(x + (size_t)(m < M ? m : M - 1) * K + kc * PW_BK + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            wr[i] = *reinterpret_cast<const u32x4*>(wgt + (size_t)(n0 + row) * K + kc * PW_BK + ch * 8);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            *reinterpret_cast<u32x4*>(sx + (buf * PW_BM + row) * PW_LS + ch * 8) = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            *reinterpret_cast<u32x4*>(sw + (buf * BN + row) * PW_LS + ch * 8) = wr[i];
+        }
+    };
+
+    f32x16 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nk) load_tiles(it + 1);
+        const bf16_t* bx = sx + (buf * PW_BM + w * 32 + c) * PW_LS + 8 * h;
+        const bf16_t* bw = sw + (buf * BN + c) * PW_LS + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < PW_BK / 16; ++ks) {
+            const bf16x8 b = lds8(bx + 16 * ks);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) mma16(acc[ct], lds8(bw + ct * 32 * PW_LS + 16 * ks), b);
+        }
+        if (it + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue on the accumulators: lane = pixel m0 + 32w + c, register quad q of tile ct = channels n0+32ct+8q+4h..+3
+    bf16_t* so = reinterpret_cast<bf16_t*>(smem_raw) + w * 32 * OS;     // the tile buffers are idle now
+    const int m = m0 + w * 32 + c;
+    const bool mok = m < M;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int co = 32 * ct + 8 * q + 4 * h;
+            const float4 sc = *reinterpret_cast<const float4*>(scale + n0 + co);
+            const float4 sh = *reinterpret_cast<const float4*>(shift + n0 + co);
+            float v[4] = {acc[ct][4 * q] * sc.x + sh.x, acc[ct][4 * q + 1] * sc.y + sh.y,
+                          acc[ct][4 * q + 2] * sc.z + sh.z, acc[ct][4 * q + 3] * sc.w + sh.w};
+            if (res != nullptr) {
+                const u32x2 rr = *reinterpret_cast<const u32x2*>(res + (size_t)(mok ? m : M - 1) * N + n0 + co);
+                v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);
+                v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+            }
+            if (relu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+            }
+            u32x2 t;
+            t[0] = pack2_bf16(v[0], v[1]);
+            t[1] = pack2_bf16(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(so + c * OS + co) = t;
+        }
+    }
+    constexpr int CPP = BN / 8;                           // 16-byte chunks per pixel
+#pragma unroll
+    for (int i = 0; i < 32 * CPP / 64; ++i) {
+        const int id = lane + 64 * i, px = id / CPP, ch = id - px * CPP;
+        const u32x4 t = *reinterpret_cast<const u32x4*>(so + px * OS + ch * 8);
+        const int mm = m0 + w * 32 + px;
+        if (mm < M) *reinterpret_cast<u32x4*>(y + (size_t)mm * N + n0 + ch * 8) = t;
+    }
+}
+
+template <int BN>
+int launch_pw_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res, void* y, int M,
+                  int K, int N, int relu, hipStream_t st) {
+    const int MT = (M + PW_BM - 1) / PW_BM, NT = N / BN;
+    const size_t tiles = (size_t)2 * (PW_BM + BN) * PW_LS * sizeof(bf16_t);
+    const size_t outb = (size_t)4 * 32 * (BN + 8) * sizeof(bf16_t);
+    const size_t lds = tiles > outb ? tiles : outb;
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void*)pw_conv_fwd_kernel<BN>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(pw_conv_fwd_kernel<BN>, dim3((unsigned)(MT * NT)), dim3(256), lds, st, (const bf16_t*)x,
+                       (const bf16_t*)w, scale, shift, (const bf16_t*)res, (bf16_t*)y, M, K, N, relu, MT, NT);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int adil_pw_conv_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res,
+                                void* y, int M, int K, int N, int relu, void* stream) {
+    ADIL_ENTER();
+    if (!x || !w || !scale || !shift || !y || M <= 0 || K <= 0 || N <= 0 || (K % PW_BK) || (N % 64)) return ADIL_EINVAL;
+    if (N % 128 == 0) return launch_pw_fwd<128>(x, w, scale, shift, res, y, M, K, N, relu, (hipStream_t)stream);
+    return launch_pw_fwd<64>(x, w, scale, shift, res, y, M, K, N, relu, (hipStream_t)stream);
+}

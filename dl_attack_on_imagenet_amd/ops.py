@@ -366,6 +366,54 @@ def affine_act(x: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = 
 
 
 # --------------------------------------------------------------------------- #
+class PointwiseConvFunction(torch.autograd.Function):
+    """y = act(conv1x1(x) * scale + shift (+ res)) on channels_last bf16 tensors as ONE kernel (adil_pw_conv_fwd: the
+    GEMM with the epilogue applied to its accumulators).  The frozen network only needs input gradients: backward is
+    the epilogue backward (adil_affine_act_bwd) and one GEMM against the weight."""
+
+    @staticmethod
+    def forward(ctx, x, res, w2d, scale, shift, relu):
+        lib = _lib.load()
+        b, cin, h, w = x.shape
+        cout = w2d.shape[0]
+        x2 = x.permute(0, 2, 3, 1)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        r2 = None
+        if res is not None:
+            r2 = res.permute(0, 2, 3, 1)
+            if not r2.is_contiguous():
+                r2 = r2.contiguous()
+        y = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device)
+        _lib.check(lib.adil_pw_conv_fwd(_ptr(x2), _ptr(w2d), _ptr(scale), _ptr(shift), _ptr(r2), _ptr(y), b * h * w, cin, cout,
+                                        int(relu), _stream()), "adil_pw_conv_fwd")
+        ctx.save_for_backward(y if relu else None, scale, w2d)
+        ctx.meta = (bool(relu), res is not None)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        y, scale, w2d = ctx.saved_tensors
+        relu, has_res = ctx.meta
+        g2 = g.permute(0, 2, 3, 1)
+        if not g2.is_contiguous() or g2.dtype != torch.bfloat16:
+            g2 = g2.to(torch.bfloat16).contiguous()
+        b, h, w, cout = g2.shape
+        gz = torch.empty_like(g2)
+        gres = torch.empty_like(g2) if has_res else None
+        _lib.check(lib.adil_affine_act_bwd(_ptr(g2), _ptr(y), _ptr(scale), _ptr(gz), _ptr(gres), g2.numel(), cout, 1,
+                                           int(relu), stream_dtype_code(g2.dtype), _stream()), "adil_affine_act_bwd")
+        gx = torch.mm(gz.reshape(b * h * w, cout), w2d).reshape(b, h, w, -1).permute(0, 3, 1, 2)
+        return gx, (gres.permute(0, 3, 1, 2) if has_res else None), None, None, None, None
+
+
+def pointwise_conv_affine(x: Tensor, w2d: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = None,
+                          relu: bool = True) -> Tensor:
+    return PointwiseConvFunction.apply(x, res, w2d, scale, shift, relu)
+
+
+# --------------------------------------------------------------------------- #
 def pack_stem_weights(weight: Tensor) -> Tuple[Tensor, Tensor]:
     """(64,3,7,7) conv weight -> the two bf16 layouts of include/adil_hip.h: w_fwd [64][7][8][4], w_bwd [4][49][64]."""
     if tuple(weight.shape) != (64, 3, 7, 7):

@@ -415,6 +415,11 @@ class _ConvAffine(nn.Module):
 
     def forward(self, x, res=None):
         from . import ops
+        if (self.pointwise and x.is_cuda and x.dtype == torch.bfloat16 and self.conv.in_channels % 64 == 0
+                and self.conv.out_channels % 64 == 0):
+            w2d = self.conv.weight.reshape(self.conv.out_channels, self.conv.in_channels)
+            if w2d.is_contiguous():                                      # (Cout, Cin): true for either memory format
+                return ops.pointwise_conv_affine(x, w2d, self.scale, self.shift, res=res, relu=self.relu)
         return ops.affine_act(self._conv(x), self.scale.float(), self.shift.float(), res=res, relu=self.relu)
 
 

@@ -162,6 +162,13 @@ int adil_stem_pool_bwd(const void* g, const uint8_t* idx, const void* p, const f
 int adil_stem_conv_bwd(const void* gy, const void* w_bwd, float inv_std0, float inv_std1, float inv_std2, void* gx,
                        int gx_dtype, int B, int H, int W, void* stream);
 
+/* Pointwise (1x1, stride 1) convolution of the frozen network on channels_last storage, with the eval-BatchNorm /
+ * residual / ReLU epilogue applied to the accumulators (bf16 in/out, fp32 accumulate):
+ *     y[M][N] = act( (x[M][K] . w[N][K]^T) * scale[n] + shift[n] (+ res[M][N]) ),  M = B*H*W, K = Cin, N = Cout
+ * K % 64 == 0, N % 64 == 0; res may be NULL; relu = 0/1. */
+int adil_pw_conv_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res, void* y, int M,
+                     int K, int N, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

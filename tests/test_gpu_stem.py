@@ -121,3 +121,29 @@ def test_fused_stem_resnet_matches_unfused():
     cos = lambda a, b: float(F.cosine_similarity(a.float().flatten(), b.float().flatten(), dim=0))
     c0, c1 = cos(g0, gr), cos(g1, gr)
     assert c1 >= c0 - 0.02, (c0, c1)
+
+
+@pytest.mark.parametrize("m,k,n", [(128, 64, 64), (300, 64, 256), (1000, 256, 64), (129, 512, 128), (4096, 128, 512),
+                                   (512 * 49, 2048, 512)])
+@pytest.mark.parametrize("relu,has_res", [(True, False), (True, True), (False, False)])
+def test_pointwise_conv_fused_epilogue(m, k, n, relu, has_res):
+    """adil_pw_conv_fwd against an fp32 matmul + affine + residual + ReLU on the same bf16 operands."""
+    o = ops()
+    lib = __import__("dl_attack_on_imagenet_amd._lib", fromlist=["x"]).load()
+    gen = torch.Generator().manual_seed(m + k + n)
+    x = torch.randn(m, k, generator=gen).bfloat16().to(DEV)
+    w = (torch.randn(n, k, generator=gen) / k ** 0.5).bfloat16().to(DEV)
+    scale = (0.5 + torch.rand(n, generator=gen)).to(DEV)
+    shift = (torch.randn(n, generator=gen) * 0.3).to(DEV)
+    res = torch.randn(m, n, generator=gen).bfloat16().to(DEV) if has_res else None
+    y = torch.full((m + 3, n), 7.0, dtype=torch.bfloat16, device=DEV)
+    assert lib.adil_pw_conv_fwd(o._ptr(x), o._ptr(w), o._ptr(scale), o._ptr(shift), o._ptr(res), o._ptr(y), m, k, n, int(relu),
+                                o._stream()) == 0
+    ref = (x.float() @ w.float().t()) * scale + shift
+    if has_res:
+        ref = ref + res.float()
+    if relu:
+        ref = torch.relu(ref)
+    err = (y[:m].float() - ref).abs()
+    assert bool((err <= 2 ** -7 * ref.abs() + 2e-3).all()), float(err.max())
+    assert bool((y[m:] == 7.0).all())
