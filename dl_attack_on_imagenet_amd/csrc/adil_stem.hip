@@ -418,7 +418,7 @@ namespace {
 #define PW_LS (PW_BK + 8)              // LDS row stride (elements): 144 B = 9 x 16 B
 
 template <int BN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void pw_conv_fwd_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void pw_conv_fwd_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ wgt, const float* __restrict__ scale,
     const float* __restrict__ shift, const bf16_t* __restrict__ res, bf16_t* __restrict__ y, int M, int K, int N,
     int relu, int MT, int NT) {
@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     constexpr int WCH = BN * PW_BK / 8 / 256;            // ... of the W tile (4 or 2)
     constexpr int OS = BN + 8;                           // transposed-output pixel stride (elements)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16_t* sx = reinterpret_cast<bf16_t*>(smem_raw);    // [2][128][PW_LS]
-    bf16_t* sw = sx + 2 * PW_BM * PW_LS;                 // [2][BN][PW_LS]
+    bf16_t* sx = reinterpret_cast<bf16_t*>(smem_raw);    // [128][PW_LS]   (single buffer: the next chunk waits in
+    bf16_t* sw = sx + PW_BM * PW_LS;                     // [BN][PW_LS]     registers; 37 KB -> 3-4 workgroups per CU)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     // workgroups are dealt round-robin to the 8 XCDs: consecutive workgroups of ONE XCD share the pixel tile, so the
     // NT reads of an X tile meet in that XCD's L2
@@ -443,14 +443,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     }
     const int m0 = mt * PW_BM, n0 = nt * BN;
     const int nk = K / PW_BK;
+    const int m = m0 + w * 32 + c;                       // this lane's pixel in the epilogue
+    const bool mok = m < M;
 
     u32x4 xr[XCH], wr[WCH];
     auto load_tiles = [&](int kc) {
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-            const int m = m0 + row;
-            xr[i] = *reinterpret_cast<const u32x4*>(x + (size_t)(m < M ? m : M - 1) * K + kc * PW_BK + ch * 8);
+            const int mm = m0 + row;
+            xr[i] = *reinterpret_cast<const u32x4*>(x + (size_t)(mm < M ? mm : M - 1) * K + kc * PW_BK + ch * 8);
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
@@ -458,45 +460,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
             wr[i] = *reinterpret_cast<const u32x4*>(wgt + (size_t)(n0 + row) * K + kc * PW_BK + ch * 8);
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&]() {
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-            *reinterpret_cast<u32x4*>(sx + (buf * PW_BM + row) * PW_LS + ch * 8) = xr[i];
+            *reinterpret_cast<u32x4*>(sx + row * PW_LS + ch * 8) = xr[i];
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-            *reinterpret_cast<u32x4*>(sw + (buf * BN + row) * PW_LS + ch * 8) = wr[i];
+            *reinterpret_cast<u32x4*>(sw + row * PW_LS + ch * 8) = wr[i];
         }
     };
 
+    load_tiles(0);
+    // the residual does not depend on the GEMM: its loads fly under the whole K loop
+    u32x2 rr[CT][4];
+    if (res != nullptr) {
+        const bf16_t* rp = res + (size_t)(mok ? m : M - 1) * N + n0 + 4 * h;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rr[ct][q] = *reinterpret_cast<const u32x2*>(rp + 32 * ct + 8 * q);
+    }
     f32x16 acc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
     for (int it = 0; it < nk; ++it) {
-        const int buf = it & 1;
+        store_tiles();
         if (it + 1 < nk) load_tiles(it + 1);
-        const bf16_t* bx = sx + (buf * PW_BM + w * 32 + c) * PW_LS + 8 * h;
-        const bf16_t* bw = sw + (buf * BN + c) * PW_LS + 8 * h;
+        __syncthreads();
+        const bf16_t* bx = sx + (w * 32 + c) * PW_LS + 8 * h;
+        const bf16_t* bw = sw + c * PW_LS + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < PW_BK / 16; ++ks) {
             const bf16x8 b = lds8(bx + 16 * ks);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) mma16(acc[ct], lds8(bw + ct * 32 * PW_LS + 16 * ks), b);
         }
-        if (it + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
     }
-    // epilogue on the accumulators: lane = pixel m0 + 32w + c, register quad q of tile ct = channels n0+32ct+8q+4h..+3
+    // epilogue on the accumulators: lane = pixel m, register quad q of tile ct = channels n0 + 32ct + 8q + 4h .. +3
     bf16_t* so = reinterpret_cast<bf16_t*>(smem_raw) + w * 32 * OS;     // the tile buffers are idle now
-    const int m = m0 + w * 32 + c;
-    const bool mok = m < M;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
@@ -507,9 +514,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
             float v[4] = {acc[ct][4 * q] * sc.x + sh.x, acc[ct][4 * q + 1] * sc.y + sh.y,
                           acc[ct][4 * q + 2] * sc.z + sh.z, acc[ct][4 * q + 3] * sc.w + sh.w};
             if (res != nullptr) {
-                const u32x2 rr = *reinterpret_cast<const u32x2*>(res + (size_t)(mok ? m : M - 1) * N + n0 + co);
-                v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);
-                v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+                v[0] += __uint_as_float(rr[ct][q][0] << 16); v[1] += __uint_as_float(rr[ct][q][0] & 0xffff0000u);
+                v[2] += __uint_as_float(rr[ct][q][1] << 16); v[3] += __uint_as_float(rr[ct][q][1] & 0xffff0000u);
             }
             if (relu) {
 #pragma unroll
@@ -535,7 +541,7 @@ template <int BN>
 int launch_pw_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res, void* y, int M,
                   int K, int N, int relu, hipStream_t st) {
     const int MT = (M + PW_BM - 1) / PW_BM, NT = N / BN;
-    const size_t tiles = (size_t)2 * (PW_BM + BN) * PW_LS * sizeof(bf16_t);
+    const size_t tiles = (size_t)(PW_BM + BN) * PW_LS * sizeof(bf16_t);
     const size_t outb = (size_t)4 * 32 * (BN + 8) * sizeof(bf16_t);
     const size_t lds = tiles > outb ? tiles : outb;
     if (lds > 48 * 1024) {
