@@ -537,6 +537,141 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void p
     }
 }
 
+// Input gradient of the same layer, again ONE kernel:  with v = g (+ g2), mask = [y > 0] (all ones without ReLU),
+//     gres[M][N] = v * mask                      (gradient of the residual input; optional)
+//     gx[M][K]   = (v * mask * scale[n]) . W     (W given transposed: wt[K][N], so the reduction index n is contiguous)
+// The epilogue backward is applied to the X-operand chunk on its way from registers to LDS (it would otherwise be a
+// separate kernel writing and re-reading an M x N tensor), and g2 lets the caller hand over the two gradients that
+// meet at a residual join without adding them first (autograd's add kernels were 3 ms of a 46 ms step).
+template <int BO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BO == 128 ? 2 : 3))) void pw_conv_bwd_kernel(
+    const bf16_t* __restrict__ g, const bf16_t* __restrict__ g2, const bf16_t* __restrict__ y,
+    const float* __restrict__ scale, const bf16_t* __restrict__ wt, bf16_t* __restrict__ gx, bf16_t* __restrict__ gres,
+    int M, int K, int N, int relu, int MT, int OT) {
+    constexpr int CT = BO / 32;
+    constexpr int XCH = PW_BM * PW_BK / 8 / 256;         // 4
+    constexpr int WCH = BO * PW_BK / 8 / 256;
+    constexpr int OS = BO + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sx = reinterpret_cast<bf16_t*>(smem_raw);    // [128][PW_LS]  gz chunk
+    bf16_t* sw = sx + PW_BM * PW_LS;                     // [BO][PW_LS]   wt chunk
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    int mt, ot;
+    if ((MT & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        ot = j % OT;
+        mt = (j / OT) * 8 + xcd;
+    } else {
+        ot = blockIdx.x % OT;
+        mt = blockIdx.x / OT;
+    }
+    const int m0 = mt * PW_BM, k0 = ot * BO;
+    const int nn = N / PW_BK;
+    const bool write_res = (gres != nullptr) && (ot == 0);
+
+    u32x4 gr[XCH], hr[XCH], yr[XCH], wr[WCH];
+    auto load_tiles = [&](int nc) {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            const int mm = m0 + row;
+            const size_t at = (size_t)(mm < M ? mm : M - 1) * N + nc * PW_BK + ch * 8;
+            gr[i] = *reinterpret_cast<const u32x4*>(g + at);
+            if (g2 != nullptr) hr[i] = *reinterpret_cast<const u32x4*>(g2 + at);
+            if (relu) yr[i] = *reinterpret_cast<const u32x4*>(y + at);
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            wr[i] = *reinterpret_cast<const u32x4*>(wt + (size_t)(k0 + row) * N + nc * PW_BK + ch * 8);
+        }
+    };
+    auto store_tiles = [&](int nc) {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            float v[8], t8[8];
+            unpack8(gr[i], v);
+            if (g2 != nullptr) {
+                unpack8(hr[i], t8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += t8[j];
+            }
+            if (relu) {
+                unpack8(yr[i], t8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = t8[j] > 0.0f ? v[j] : 0.0f;
+            }
+            const int mm = m0 + row;
+            if (write_res && mm < M) *reinterpret_cast<u32x4*>(gres + (size_t)mm * N + nc * PW_BK + ch * 8) = pack8(v);
+            const float4 s0 = *reinterpret_cast<const float4*>(scale + nc * PW_BK + ch * 8);
+            const float4 s1 = *reinterpret_cast<const float4*>(scale + nc * PW_BK + ch * 8 + 4);
+            v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w;
+            v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w;
+            *reinterpret_cast<u32x4*>(sx + row * PW_LS + ch * 8) = pack8(v);
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            *reinterpret_cast<u32x4*>(sw + row * PW_LS + ch * 8) = wr[i];
+        }
+    };
+
+    load_tiles(0);
+    f32x16 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+    for (int it = 0; it < nn; ++it) {
+        store_tiles(it);
+        if (it + 1 < nn) load_tiles(it + 1);
+        __syncthreads();
+        const bf16_t* bx = sx + (w * 32 + c) * PW_LS + 8 * h;
+        const bf16_t* bw = sw + c * PW_LS + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < PW_BK / 16; ++ks) {
+            const bf16x8 b = lds8(bx + 16 * ks);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) mma16(acc[ct], lds8(bw + ct * 32 * PW_LS + 16 * ks), b);
+        }
+        __syncthreads();
+    }
+    bf16_t* so = reinterpret_cast<bf16_t*>(smem_raw) + w * 32 * OS;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u32x2 t;
+            t[0] = pack2_bf16(acc[ct][4 * q], acc[ct][4 * q + 1]);
+            t[1] = pack2_bf16(acc[ct][4 * q + 2], acc[ct][4 * q + 3]);
+            *reinterpret_cast<u32x2*>(so + c * OS + 32 * ct + 8 * q + 4 * h) = t;
+        }
+    }
+    constexpr int CPP = BO / 8;
+#pragma unroll
+    for (int i = 0; i < 32 * CPP / 64; ++i) {
+        const int id = lane + 64 * i, px = id / CPP, ch = id - px * CPP;
+        const u32x4 t = *reinterpret_cast<const u32x4*>(so + px * OS + ch * 8);
+        const int mm = m0 + w * 32 + px;
+        if (mm < M) *reinterpret_cast<u32x4*>(gx + (size_t)mm * K + k0 + ch * 8) = t;
+    }
+}
+
+template <int BO>
+int launch_pw_bwd(const void* g, const void* g2, const void* y, const float* scale, const void* wt, void* gx, void* gres,
+                  int M, int K, int N, int relu, hipStream_t st) {
+    const int MT = (M + PW_BM - 1) / PW_BM, OT = K / BO;
+    const size_t tiles = (size_t)(PW_BM + BO) * PW_LS * sizeof(bf16_t);
+    const size_t outb = (size_t)4 * 32 * (BO + 8) * sizeof(bf16_t);
+    const size_t lds = tiles > outb ? tiles : outb;
+    hipLaunchKernelGGL(pw_conv_bwd_kernel<BO>, dim3((unsigned)(MT * OT)), dim3(256), lds, st, (const bf16_t*)g,
+                       (const bf16_t*)g2, (const bf16_t*)y, scale, (const bf16_t*)wt, (bf16_t*)gx, (bf16_t*)gres, M, K, N,
+                       relu, MT, OT);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int BN>
 int launch_pw_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res, void* y, int M,
                   int K, int N, int relu, hipStream_t st) {
@@ -556,6 +691,14 @@ int launch_pw_fwd(const void* x, const void* w, const float* scale, const float*
 }
 
 }  // namespace
+
+extern "C" int adil_pw_conv_bwd(const void* g, const void* g2, const void* y, const float* scale, const void* wt, void* gx,
+                                void* gres, int M, int K, int N, int relu, void* stream) {
+    ADIL_ENTER();
+    if (!g || !scale || !wt || !gx || (relu && !y) || M <= 0 || K <= 0 || N <= 0 || (N % PW_BK) || (K % 64)) return ADIL_EINVAL;
+    if (K % 128 == 0) return launch_pw_bwd<128>(g, g2, y, scale, wt, gx, gres, M, K, N, relu, (hipStream_t)stream);
+    return launch_pw_bwd<64>(g, g2, y, scale, wt, gx, gres, M, K, N, relu, (hipStream_t)stream);
+}
 
 extern "C" int adil_pw_conv_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res,
                                 void* y, int M, int K, int N, int relu, void* stream) {

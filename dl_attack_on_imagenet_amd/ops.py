@@ -368,12 +368,16 @@ def affine_act(x: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = 
 # --------------------------------------------------------------------------- #
 class PointwiseConvFunction(torch.autograd.Function):
     """y = act(conv1x1(x) * scale + shift (+ res)) on channels_last bf16 tensors as ONE kernel (adil_pw_conv_fwd: the
-    GEMM with the epilogue applied to its accumulators).  The frozen network only needs input gradients: backward is
-    the epilogue backward (adil_affine_act_bwd) and one GEMM against the weight."""
+    GEMM with the epilogue applied to its accumulators), and its input gradient as ONE kernel (adil_pw_conv_bwd: the
+    epilogue backward applied to the GEMM operand on its way into LDS).
+    With `twin=True` the forward returns the result twice (same storage): a residual block hands one to its main
+    path and one to its skip path, so that the two gradients arrive here separately and are summed inside the
+    backward kernel instead of by an autograd add kernel."""
 
     @staticmethod
-    def forward(ctx, x, res, w2d, scale, shift, relu):
+    def forward(ctx, x, res, w2d, wt2d, scale, shift, relu, twin):
         lib = _lib.load()
+        ctx.set_materialize_grads(False)
         b, cin, h, w = x.shape
         cout = w2d.shape[0]
         x2 = x.permute(0, 2, 3, 1)
@@ -387,30 +391,40 @@ class PointwiseConvFunction(torch.autograd.Function):
         y = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device)
         _lib.check(lib.adil_pw_conv_fwd(_ptr(x2), _ptr(w2d), _ptr(scale), _ptr(shift), _ptr(r2), _ptr(y), b * h * w, cin, cout,
                                         int(relu), _stream()), "adil_pw_conv_fwd")
-        ctx.save_for_backward(y if relu else None, scale, w2d)
-        ctx.meta = (bool(relu), res is not None)
-        return y.permute(0, 3, 1, 2)
+        ctx.save_for_backward(y if relu else None, scale, wt2d)
+        ctx.meta = (bool(relu), res is not None, cin)
+        out = y.permute(0, 3, 1, 2)
+        if twin:
+            return out, out.view_as(out)
+        return out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_twin=None):
         lib = _lib.load()
-        y, scale, w2d = ctx.saved_tensors
-        relu, has_res = ctx.meta
-        g2 = g.permute(0, 2, 3, 1)
-        if not g2.is_contiguous() or g2.dtype != torch.bfloat16:
-            g2 = g2.to(torch.bfloat16).contiguous()
+        y, scale, wt2d = ctx.saved_tensors
+        relu, has_res, cin = ctx.meta
+        if g is None:
+            g, g_twin = g_twin, None
+        if g is None:
+            return (None,) * 8
+
+        def nhwc(t):
+            t2 = t.permute(0, 2, 3, 1)
+            return t2 if (t2.is_contiguous() and t2.dtype == torch.bfloat16) else t2.to(torch.bfloat16).contiguous()
+
+        g2 = nhwc(g)
+        gt = nhwc(g_twin) if g_twin is not None else None
         b, h, w, cout = g2.shape
-        gz = torch.empty_like(g2)
+        gx = torch.empty((b, h, w, cin), dtype=torch.bfloat16, device=g2.device)
         gres = torch.empty_like(g2) if has_res else None
-        _lib.check(lib.adil_affine_act_bwd(_ptr(g2), _ptr(y), _ptr(scale), _ptr(gz), _ptr(gres), g2.numel(), cout, 1,
-                                           int(relu), stream_dtype_code(g2.dtype), _stream()), "adil_affine_act_bwd")
-        gx = torch.mm(gz.reshape(b * h * w, cout), w2d).reshape(b, h, w, -1).permute(0, 3, 1, 2)
-        return gx, (gres.permute(0, 3, 1, 2) if has_res else None), None, None, None, None
+        _lib.check(lib.adil_pw_conv_bwd(_ptr(g2), _ptr(gt), _ptr(y), _ptr(scale), _ptr(wt2d), _ptr(gx), _ptr(gres), b * h * w,
+                                        cin, cout, int(relu), _stream()), "adil_pw_conv_bwd")
+        return (gx.permute(0, 3, 1, 2), gres.permute(0, 3, 1, 2) if has_res else None) + (None,) * 6
 
 
-def pointwise_conv_affine(x: Tensor, w2d: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = None,
-                          relu: bool = True) -> Tensor:
-    return PointwiseConvFunction.apply(x, res, w2d, scale, shift, relu)
+def pointwise_conv_affine(x: Tensor, w2d: Tensor, wt2d: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = None,
+                          relu: bool = True, twin: bool = False):
+    return PointwiseConvFunction.apply(x, res, w2d, wt2d, scale, shift, relu, twin)
 
 
 # --------------------------------------------------------------------------- #

@@ -402,6 +402,8 @@ class _ConvAffine(nn.Module):
         # a 1x1 / stride-1 convolution of a channels_last tensor IS a row-major GEMM (B*H*W x Cin) @ (Cin x Cout)
         self.pointwise = (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
                           and conv.groups == 1 and conv.bias is None)
+        if self.pointwise:      # (Cin, Cout) copy for the input-gradient kernel; 2-D, so channels_last leaves it alone
+            self.register_buffer('wt2d', conv.weight.detach().reshape(conv.out_channels, conv.in_channels).t().contiguous())
 
     def _conv(self, x):
         if self.pointwise and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last):
@@ -413,14 +415,20 @@ class _ConvAffine(nn.Module):
             return y2.reshape(b, h, w, -1).permute(0, 3, 1, 2)                         # channels_last storage
         return self.conv(x)
 
-    def forward(self, x, res=None):
+    def fused_pointwise(self, x) -> bool:
+        return (self.pointwise and x.is_cuda and x.dtype == torch.bfloat16 and self.conv.in_channels % 64 == 0
+                and self.conv.out_channels % 64 == 0)
+
+    def forward(self, x, res=None, twin=False):
+        """twin=True returns the result twice (see ops.PointwiseConvFunction): only valid when fused_pointwise(x)."""
         from . import ops
-        if (self.pointwise and x.is_cuda and x.dtype == torch.bfloat16 and self.conv.in_channels % 64 == 0
-                and self.conv.out_channels % 64 == 0):
+        if self.fused_pointwise(x):
             w2d = self.conv.weight.reshape(self.conv.out_channels, self.conv.in_channels)
             if w2d.is_contiguous():                                      # (Cout, Cin): true for either memory format
-                return ops.pointwise_conv_affine(x, w2d, self.scale, self.shift, res=res, relu=self.relu)
-        return ops.affine_act(self._conv(x), self.scale.float(), self.shift.float(), res=res, relu=self.relu)
+                return ops.pointwise_conv_affine(x, w2d, self.wt2d, self.scale, self.shift, res=res, relu=self.relu,
+                                                 twin=twin)
+        y = ops.affine_act(self._conv(x), self.scale.float(), self.shift.float(), res=res, relu=self.relu)
+        return (y, y) if twin else y
 
 
 class _FusedResBlock(nn.Module):
@@ -436,10 +444,13 @@ class _FusedResBlock(nn.Module):
         self.down = None if block.downsample is None else _ConvAffine(block.downsample[0], block.downsample[1], False)
 
     def forward(self, x):
-        idt = x if self.down is None else self.down(x)
-        out = self.c1(x)
+        """x is a tensor or a (main, skip) pair of the same activation (see _ConvAffine.forward, twin=True): the pair
+        keeps the two gradients of the residual join apart until the producing kernel's backward adds them."""
+        xm, xs = x if isinstance(x, tuple) else (x, x)
+        idt = xs if self.down is None else self.down(xs)
+        out = self.c1(xm)
         if self.bottleneck:
-            return self.c3(self.c2(out), res=idt)
+            return self.c3(self.c2(out), res=idt, twin=True)
         return self.c2(out, res=idt)
 
 
@@ -489,6 +500,8 @@ class FusedResNet(nn.Module):
     def forward(self, x):
         x = self.fstem(x) if self.fstem is not None else self.maxpool(self.stem(x))
         x = self.layers(x)
+        if isinstance(x, tuple):
+            x = x[0]
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 

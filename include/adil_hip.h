@@ -168,6 +168,11 @@ int adil_stem_conv_bwd(const void* gy, const void* w_bwd, float inv_std0, float 
  * K % 64 == 0, N % 64 == 0; res may be NULL; relu = 0/1. */
 int adil_pw_conv_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res, void* y, int M,
                      int K, int N, int relu, void* stream);
+/* Input gradient of adil_pw_conv_fwd.  v = g (+ g2 if not NULL: the two gradients meeting at a residual join),
+ * mask = [y > 0] if relu else 1:   gres[M][N] = v * mask (optional),   gx[M][K] = (v * mask * scale[n]) . w,
+ * with the weight given transposed, wt[K][N].  N % 64 == 0, K % 64 == 0. */
+int adil_pw_conv_bwd(const void* g, const void* g2, const void* y, const float* scale, const void* wt, void* gx, void* gres,
+                     int M, int K, int N, int relu, void* stream);
 
 #ifdef __cplusplus
 }

@@ -147,3 +147,60 @@ def test_pointwise_conv_fused_epilogue(m, k, n, relu, has_res):
     err = (y[:m].float() - ref).abs()
     assert bool((err <= 2 ** -7 * ref.abs() + 2e-3).all()), float(err.max())
     assert bool((y[m:] == 7.0).all())
+
+
+@pytest.mark.parametrize("m,k,n", [(128, 64, 64), (300, 64, 256), (1000, 256, 64), (129, 128, 512), (4096, 512, 128),
+                                   (512 * 49, 512, 2048)])
+@pytest.mark.parametrize("relu,has_res,has_g2", [(True, False, False), (True, True, True), (False, False, False),
+                                                  (True, True, False)])
+def test_pointwise_conv_fused_backward(m, k, n, relu, has_res, has_g2):
+    """adil_pw_conv_bwd against fp32: gres = (g+g2)*[y>0], gx = (gres*scale) @ W on the same bf16 operands."""
+    o = ops()
+    lib = __import__("dl_attack_on_imagenet_amd._lib", fromlist=["x"]).load()
+    gen = torch.Generator().manual_seed(m + 2 * k + n)
+    g = torch.randn(m, n, generator=gen).bfloat16().to(DEV)
+    g2 = torch.randn(m, n, generator=gen).bfloat16().to(DEV) if has_g2 else None
+    y = torch.relu(torch.randn(m, n, generator=gen)).bfloat16().to(DEV)
+    w = (torch.randn(n, k, generator=gen) / n ** 0.5).bfloat16().to(DEV)
+    wt = w.t().contiguous()
+    scale = (0.5 + torch.rand(n, generator=gen)).to(DEV)
+    gx = torch.full((m + 2, k), 7.0, dtype=torch.bfloat16, device=DEV)
+    gres = torch.full((m + 2, n), 7.0, dtype=torch.bfloat16, device=DEV) if has_res else None
+    assert lib.adil_pw_conv_bwd(o._ptr(g), o._ptr(g2), o._ptr(y), o._ptr(scale), o._ptr(wt), o._ptr(gx), o._ptr(gres), m, k, n,
+                                int(relu), o._stream()) == 0
+    v = g.float() + (g2.float() if has_g2 else 0.0)
+    if relu:
+        v = v * (y > 0)
+    if has_res:
+        assert bool(((gres[:m].float() - v).abs() <= 2 ** -7 * v.abs() + 1e-6).all())
+        assert bool((gres[m:] == 7.0).all())
+    gz = (v.bfloat16().float() if has_res or True else v) * scale      # the kernel scales the fp32 value, rounds once
+    ref = (v * scale).bfloat16().float() @ w.float()
+    err = (gx[:m].float() - ref).abs()
+    assert bool((err <= 2 ** -6 * ref.abs() + 3e-2).all()), float(err.max())
+    assert float(err.mean()) < 4e-3
+    assert bool((gx[m:] == 7.0).all())
+
+
+def test_fused_resnet50_gradient_matches_fp32():
+    """ResNet-50 (bottlenecks: fused pointwise forward/backward kernels, twin residual gradients, stem kernels) against
+    the fp32 network with the same weights: input gradient direction and logits."""
+    from dl_attack_on_imagenet_amd import zoo
+    ref = zoo.build_classifier("resnet50", num_classes=10, seed=5, device=DEV, dtype=torch.float32)
+    kw = dict(num_classes=10, seed=5, device=DEV, dtype=torch.bfloat16, channels_last=True)
+    m0 = zoo.build_classifier("resnet50", **kw)                                     # plain bf16 torch path
+    m1 = zoo.build_classifier("resnet50", fuse_bn_act=True, fuse_stem=True, **kw)
+    gen = torch.Generator().manual_seed(0)
+    x = torch.rand(4, 3, 64, 64, generator=gen).to(DEV).bfloat16()
+    xr, x0, x1 = (x.float().requires_grad_(True), x.clone().requires_grad_(True), x.clone().requires_grad_(True))
+    lr, l0, l1 = ref(xr), m0(x0).float(), m1(x1).float()
+    e0, e1 = float((l0 - lr).abs().mean().detach()), float((l1 - lr).abs().mean().detach())
+    assert e1 <= 1.5 * e0 + 1e-3, (e0, e1)
+    (gr,) = torch.autograd.grad(lr.square().sum(), xr)
+    (g0,) = torch.autograd.grad(l0.square().sum(), x0)
+    (g1,) = torch.autograd.grad(l1.square().sum(), x1)
+    cos = lambda a, b: float(F.cosine_similarity(a.float().flatten(), b.float().flatten(), dim=0))
+    c0, c1 = cos(g0, gr), cos(g1, gr)
+    assert c1 >= c0 - 0.02, (c0, c1)
+    n0, n1, nr = float(g0.float().norm()), float(g1.float().norm()), float(gr.norm())
+    assert abs(n1 - nr) <= 2.0 * abs(n0 - nr) + 0.05 * nr, (n0, n1, nr)
