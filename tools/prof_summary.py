@@ -9,7 +9,8 @@ import sys
 
 def short(name: str) -> str:
     name = name.strip('"')
-    m = re.match(r"void\s+((?:\w+::)*)(\w+)<", name)
+    name = name.replace("(anonymous namespace)::", "")
+    m = re.match(r"(?:void\s+)?((?:\w+::)*)(\w+)[<(]", name)
     if "kernel_grouped_conv_bwd_data" in name: return "ck::grouped_conv_bwd_data_xdl"
     if "kernel_grouped_conv_fwd" in name: return "ck::grouped_conv_fwd_xdl"
     if "batch_norm_elementwise_backward_eval" in name: return "at::batch_norm_elementwise_backward_eval"
