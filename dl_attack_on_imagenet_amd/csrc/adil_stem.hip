@@ -445,6 +445,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void p
     const int nk = K / PW_BK;
     const int m = m0 + w * 32 + c;                       // this lane's pixel in the epilogue
     const bool mok = m < M;
+    __shared__ __attribute__((aligned(16))) float ssc[2 * BN];   // this tile's scale | shift (visible after the first barrier)
+    if (tid < BN) { ssc[tid] = scale[n0 + tid]; ssc[BN + tid] = shift[n0 + tid]; }
 
     u32x4 xr[XCH], wr[WCH];
     auto load_tiles = [&](int kc) {
@@ -509,8 +511,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void p
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int co = 32 * ct + 8 * q + 4 * h;
-            const float4 sc = *reinterpret_cast<const float4*>(scale + n0 + co);
-            const float4 sh = *reinterpret_cast<const float4*>(shift + n0 + co);
+            const float4 sc = *reinterpret_cast<const float4*>(ssc + co);
+            const float4 sh = *reinterpret_cast<const float4*>(ssc + BN + co);
             float v[4] = {acc[ct][4 * q] * sc.x + sh.x, acc[ct][4 * q + 1] * sc.y + sh.y,
                           acc[ct][4 * q + 2] * sc.z + sh.z, acc[ct][4 * q + 3] * sc.w + sh.w};
             if (res != nullptr) {
@@ -568,6 +570,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BO == 128 ?
     const int m0 = mt * PW_BM, k0 = ot * BO;
     const int nn = N / PW_BK;
     const bool write_res = (gres != nullptr) && (ot == 0);
+    __shared__ __attribute__((aligned(16))) float ssc[2048];     // BatchNorm scale of every reduction channel
+    for (int i = tid; i < N; i += 256) ssc[i] = scale[i];
+    __syncthreads();
 
     u32x4 gr[XCH], hr[XCH], yr[XCH], wr[WCH];
     auto load_tiles = [&](int nc) {
@@ -604,8 +609,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BO == 128 ?
             }
             const int mm = m0 + row;
             if (write_res && mm < M) *reinterpret_cast<u32x4*>(gres + (size_t)mm * N + nc * PW_BK + ch * 8) = pack8(v);
-            const float4 s0 = *reinterpret_cast<const float4*>(scale + nc * PW_BK + ch * 8);
-            const float4 s1 = *reinterpret_cast<const float4*>(scale + nc * PW_BK + ch * 8 + 4);
+            const float4 s0 = *reinterpret_cast<const float4*>(ssc + nc * PW_BK + ch * 8);
+            const float4 s1 = *reinterpret_cast<const float4*>(ssc + nc * PW_BK + ch * 8 + 4);
             v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w;
             v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w;
             *reinterpret_cast<u32x4*>(sx + row * PW_LS + ch * 8) = pack8(v);
@@ -695,7 +700,8 @@ int launch_pw_fwd(const void* x, const void* w, const float* scale, const float*
 extern "C" int adil_pw_conv_bwd(const void* g, const void* g2, const void* y, const float* scale, const void* wt, void* gx,
                                 void* gres, int M, int K, int N, int relu, void* stream) {
     ADIL_ENTER();
-    if (!g || !scale || !wt || !gx || (relu && !y) || M <= 0 || K <= 0 || N <= 0 || (N % PW_BK) || (K % 64)) return ADIL_EINVAL;
+    if (!g || !scale || !wt || !gx || (relu && !y) || M <= 0 || K <= 0 || N <= 0 || (N % PW_BK) || (K % 64) || N > 2048)
+        return ADIL_EINVAL;
     if (K % 128 == 0) return launch_pw_bwd<128>(g, g2, y, scale, wt, gx, gres, M, K, N, relu, (hipStream_t)stream);
     return launch_pw_bwd<64>(g, g2, y, scale, wt, gx, gres, M, K, N, relu, (hipStream_t)stream);
 }

@@ -417,7 +417,7 @@ class _ConvAffine(nn.Module):
 
     def fused_pointwise(self, x) -> bool:
         return (self.pointwise and x.is_cuda and x.dtype == torch.bfloat16 and self.conv.in_channels % 64 == 0
-                and self.conv.out_channels % 64 == 0)
+                and self.conv.out_channels % 64 == 0 and self.conv.out_channels <= 2048)
 
     def forward(self, x, res=None, twin=False):
         """twin=True returns the result twice (see ops.PointwiseConvFunction): only valid when fused_pointwise(x)."""

@@ -31,3 +31,21 @@ for (hw, k, n, has_res), mu in zip(shapes, mult):
     tot += t * mu; tot_floor += fl * mu
     print(f"hw {hw:3d} K {k:5d} N {n:5d} res {has_res}  {t:7.1f} us   floor@5.3TB/s {fl:7.1f} us  ({fl/t*100:4.0f}%)  x{mu}", flush=True)
 print(f"weighted total {tot/1e3:.2f} ms, floor {tot_floor/1e3:.2f} ms")
+
+print("---- input gradient (adil_pw_conv_bwd): g (+g2), y -> gres, gx")
+tot = tot_floor = 0
+for (hw, k, n, has_res), mu in zip(shapes, mult):
+    m = B * hw * hw
+    g = torch.randn(m, n, device=dev, dtype=torch.bfloat16)
+    g2 = torch.randn(m, n, device=dev, dtype=torch.bfloat16) if has_res else None
+    yy = torch.relu(torch.randn(m, n, device=dev)).bfloat16()
+    wt = torch.randn(k, n, device=dev, dtype=torch.bfloat16) * 0.05
+    sc = torch.rand(n, device=dev) + 0.5
+    gx = torch.empty(m, k, device=dev, dtype=torch.bfloat16)
+    gres = torch.empty(m, n, device=dev, dtype=torch.bfloat16) if has_res else None
+    t = timeit(lambda: lib.adil_pw_conv_bwd(ops._ptr(g), ops._ptr(g2), ops._ptr(yy), ops._ptr(sc), ops._ptr(wt), ops._ptr(gx), ops._ptr(gres), m, k, n, 1, ops._stream()))
+    byt = (m * k + m * n * (4 if has_res else 2) + n * k) * 2
+    fl = byt / 5.3e6
+    tot += t * mu; tot_floor += fl * mu
+    print(f"hw {hw:3d} K {k:5d} N {n:5d} res {has_res}  {t:7.1f} us   floor@5.3TB/s {fl:7.1f} us  ({fl/t*100:4.0f}%)  x{mu}", flush=True)
+print(f"weighted total {tot/1e3:.2f} ms, floor {tot_floor/1e3:.2f} ms")
