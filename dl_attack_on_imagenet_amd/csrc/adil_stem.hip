@@ -416,12 +416,13 @@ namespace {
 #define PW_BM 128
 #define PW_BK 64
 #define PW_LS (PW_BK + 8)              // LDS row stride (elements): 144 B = 9 x 16 B
+#define PW_PK 512                      // most input channels a fused prologue / backward epilogue supports
 
-template <int BN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void pw_conv_fwd_kernel(
+template <int BN, bool PRO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRO && BN == 128 ? 2 : 3))) void pw_conv_fwd_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ wgt, const float* __restrict__ scale,
     const float* __restrict__ shift, const bf16_t* __restrict__ res, bf16_t* __restrict__ y, int M, int K, int N,
-    int relu, int MT, int NT) {
+    int relu, int MT, int NT, const float* __restrict__ pscale, const float* __restrict__ pshift) {
     constexpr int CT = BN / 32;                          // channel tiles per wave
     constexpr int XCH = PW_BM * PW_BK / 8 / 256;         // 16-byte chunks of the X tile per thread (4)
     constexpr int WCH = BN * PW_BK / 8 / 256;            // ... of the W tile (4 or 2)
@@ -447,6 +448,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void p
     const bool mok = m < M;
     __shared__ __attribute__((aligned(16))) float ssc[2 * BN];   // this tile's scale | shift (visible after the first barrier)
     if (tid < BN) { ssc[tid] = scale[n0 + tid]; ssc[BN + tid] = shift[n0 + tid]; }
+    // optional prologue: the X operand is the RAW output of the previous (library) convolution and its eval-BatchNorm
+    // + ReLU is applied on the way from registers to LDS:  x' = relu(x * pscale[k] + pshift[k])   (K <= PW_PK)
+    __shared__ __attribute__((aligned(16))) float spro[PRO ? 2 * PW_PK : 4];
+    constexpr bool pro = PRO;
+    if (pro) {
+        for (int i = tid; i < K; i += 256) { spro[i] = pscale[i]; spro[PW_PK + i] = pshift[i]; }
+        __syncthreads();
+    }
 
     u32x4 xr[XCH], wr[WCH];
     auto load_tiles = [&](int kc) {
@@ -462,11 +471,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void p
             wr[i] = *reinterpret_cast<const u32x4*>(wgt + (size_t)(n0 + row) * K + kc * PW_BK + ch * 8);
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int kc) {
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-            *reinterpret_cast<u32x4*>(sx + row * PW_LS + ch * 8) = xr[i];
+            u32x4 t = xr[i];
+            if (pro) {
+                float v[8];
+                unpack8(t, v);
+                const float* ps = spro + kc * PW_BK + ch * 8;
+                const float4 a0 = *reinterpret_cast<const float4*>(ps), a1 = *reinterpret_cast<const float4*>(ps + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(ps + PW_PK), b1 = *reinterpret_cast<const float4*>(ps + PW_PK + 4);
+                v[0] = fmaxf(v[0] * a0.x + b0.x, 0.0f); v[1] = fmaxf(v[1] * a0.y + b0.y, 0.0f);
+                v[2] = fmaxf(v[2] * a0.z + b0.z, 0.0f); v[3] = fmaxf(v[3] * a0.w + b0.w, 0.0f);
+                v[4] = fmaxf(v[4] * a1.x + b1.x, 0.0f); v[5] = fmaxf(v[5] * a1.y + b1.y, 0.0f);
+                v[6] = fmaxf(v[6] * a1.z + b1.z, 0.0f); v[7] = fmaxf(v[7] * a1.w + b1.w, 0.0f);
+                t = pack8(v);
+            }
+            *reinterpret_cast<u32x4*>(sx + row * PW_LS + ch * 8) = t;
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
@@ -491,7 +513,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void p
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
     for (int it = 0; it < nk; ++it) {
-        store_tiles();
+        store_tiles(it);
         if (it + 1 < nk) load_tiles(it + 1);
         __syncthreads();
         const bf16_t* bx = sx + (w * 32 + c) * PW_LS + 8 * h;
@@ -549,7 +571,8 @@ template <int BO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BO == 128 ? 2 : 3))) void pw_conv_bwd_kernel(
     const bf16_t* __restrict__ g, const bf16_t* __restrict__ g2, const bf16_t* __restrict__ y,
     const float* __restrict__ scale, const bf16_t* __restrict__ wt, bf16_t* __restrict__ gx, bf16_t* __restrict__ gres,
-    int M, int K, int N, int relu, int MT, int OT) {
+    int M, int K, int N, int relu, int MT, int OT, const bf16_t* __restrict__ xin, const float* __restrict__ pscale,
+    const float* __restrict__ pshift) {
     constexpr int CT = BO / 32;
     constexpr int XCH = PW_BM * PW_BK / 8 / 256;         // 4
     constexpr int WCH = BO * PW_BK / 8 / 256;
@@ -653,44 +676,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BO == 128 ?
             *reinterpret_cast<u32x2*>(so + c * OS + 32 * ct + 8 * q + 4 * h) = t;
         }
     }
+    // optional epilogue: the forward fed this layer relu(xin * pscale + pshift) computed on the fly (xin = raw output
+    // of the previous convolution), so the gradient handed back is wrt xin:  gx * [xin*pscale+pshift > 0] * pscale
     constexpr int CPP = BO / 8;
 #pragma unroll
     for (int i = 0; i < 32 * CPP / 64; ++i) {
         const int id = lane + 64 * i, px = id / CPP, ch = id - px * CPP;
-        const u32x4 t = *reinterpret_cast<const u32x4*>(so + px * OS + ch * 8);
+        u32x4 t = *reinterpret_cast<const u32x4*>(so + px * OS + ch * 8);
         const int mm = m0 + w * 32 + px;
-        if (mm < M) *reinterpret_cast<u32x4*>(gx + (size_t)mm * K + k0 + ch * 8) = t;
+        if (mm < M) {
+            if (xin != nullptr) {
+                float v[8], xv[8];
+                unpack8(t, v);
+                unpack8(*reinterpret_cast<const u32x4*>(xin + (size_t)mm * K + k0 + ch * 8), xv);
+                const float4 a0 = *reinterpret_cast<const float4*>(pscale + k0 + ch * 8);
+                const float4 a1 = *reinterpret_cast<const float4*>(pscale + k0 + ch * 8 + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(pshift + k0 + ch * 8);
+                const float4 b1 = *reinterpret_cast<const float4*>(pshift + k0 + ch * 8 + 4);
+                const float ps[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const float pb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (xv[j] * ps[j] + pb[j] > 0.0f) ? v[j] * ps[j] : 0.0f;
+                t = pack8(v);
+            }
+            *reinterpret_cast<u32x4*>(gx + (size_t)mm * K + k0 + ch * 8) = t;
+        }
     }
 }
 
 template <int BO>
 int launch_pw_bwd(const void* g, const void* g2, const void* y, const float* scale, const void* wt, void* gx, void* gres,
-                  int M, int K, int N, int relu, hipStream_t st) {
+                  int M, int K, int N, int relu, const void* xin, const float* pscale, const float* pshift, hipStream_t st) {
     const int MT = (M + PW_BM - 1) / PW_BM, OT = K / BO;
     const size_t tiles = (size_t)(PW_BM + BO) * PW_LS * sizeof(bf16_t);
     const size_t outb = (size_t)4 * 32 * (BO + 8) * sizeof(bf16_t);
     const size_t lds = tiles > outb ? tiles : outb;
     hipLaunchKernelGGL(pw_conv_bwd_kernel<BO>, dim3((unsigned)(MT * OT)), dim3(256), lds, st, (const bf16_t*)g,
                        (const bf16_t*)g2, (const bf16_t*)y, scale, (const bf16_t*)wt, (bf16_t*)gx, (bf16_t*)gres, M, K, N,
-                       relu, MT, OT);
+                       relu, MT, OT, (const bf16_t*)xin, pscale, pshift);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
 
-template <int BN>
+template <int BN, bool PRO>
 int launch_pw_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res, void* y, int M,
-                  int K, int N, int relu, hipStream_t st) {
+                  int K, int N, int relu, const float* pscale, const float* pshift, hipStream_t st) {
     const int MT = (M + PW_BM - 1) / PW_BM, NT = N / BN;
     const size_t tiles = (size_t)(PW_BM + BN) * PW_LS * sizeof(bf16_t);
     const size_t outb = (size_t)4 * 32 * (BN + 8) * sizeof(bf16_t);
     const size_t lds = tiles > outb ? tiles : outb;
     if (lds > 48 * 1024) {
-        const hipError_t e = hipFuncSetAttribute((const void*)pw_conv_fwd_kernel<BN>,
+        const hipError_t e = hipFuncSetAttribute((const void*)pw_conv_fwd_kernel<BN, PRO>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(pw_conv_fwd_kernel<BN>, dim3((unsigned)(MT * NT)), dim3(256), lds, st, (const bf16_t*)x,
-                       (const bf16_t*)w, scale, shift, (const bf16_t*)res, (bf16_t*)y, M, K, N, relu, MT, NT);
+    hipLaunchKernelGGL((pw_conv_fwd_kernel<BN, PRO>), dim3((unsigned)(MT * NT)), dim3(256), lds, st, (const bf16_t*)x,
+                       (const bf16_t*)w, scale, shift, (const bf16_t*)res, (bf16_t*)y, M, K, N, relu, MT, NT, pscale, pshift);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
@@ -698,18 +739,28 @@ int launch_pw_fwd(const void* x, const void* w, const float* scale, const float*
 }  // namespace
 
 extern "C" int adil_pw_conv_bwd(const void* g, const void* g2, const void* y, const float* scale, const void* wt, void* gx,
-                                void* gres, int M, int K, int N, int relu, void* stream) {
+                                void* gres, int M, int K, int N, int relu, const void* xin, const float* pscale,
+                                const float* pshift, void* stream) {
     ADIL_ENTER();
     if (!g || !scale || !wt || !gx || (relu && !y) || M <= 0 || K <= 0 || N <= 0 || (N % PW_BK) || (K % 64) || N > 2048)
         return ADIL_EINVAL;
-    if (K % 128 == 0) return launch_pw_bwd<128>(g, g2, y, scale, wt, gx, gres, M, K, N, relu, (hipStream_t)stream);
-    return launch_pw_bwd<64>(g, g2, y, scale, wt, gx, gres, M, K, N, relu, (hipStream_t)stream);
+    if (xin && (!pscale || !pshift)) return ADIL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (K % 128 == 0) return launch_pw_bwd<128>(g, g2, y, scale, wt, gx, gres, M, K, N, relu, xin, pscale, pshift, st);
+    return launch_pw_bwd<64>(g, g2, y, scale, wt, gx, gres, M, K, N, relu, xin, pscale, pshift, st);
 }
 
 extern "C" int adil_pw_conv_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res,
-                                void* y, int M, int K, int N, int relu, void* stream) {
+                                void* y, int M, int K, int N, int relu, const float* pscale, const float* pshift,
+                                void* stream) {
     ADIL_ENTER();
     if (!x || !w || !scale || !shift || !y || M <= 0 || K <= 0 || N <= 0 || (K % PW_BK) || (N % 64)) return ADIL_EINVAL;
-    if (N % 128 == 0) return launch_pw_fwd<128>(x, w, scale, shift, res, y, M, K, N, relu, (hipStream_t)stream);
-    return launch_pw_fwd<64>(x, w, scale, shift, res, y, M, K, N, relu, (hipStream_t)stream);
+    if ((pscale != nullptr) != (pshift != nullptr) || (pscale && K > PW_PK)) return ADIL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (pscale) {
+        if (N % 128 == 0) return launch_pw_fwd<128, true>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, st);
+        return launch_pw_fwd<64, true>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, st);
+    }
+    if (N % 128 == 0) return launch_pw_fwd<128, false>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, st);
+    return launch_pw_fwd<64, false>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, st);
 }

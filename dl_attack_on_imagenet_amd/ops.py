@@ -367,15 +367,18 @@ def affine_act(x: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = 
 
 # --------------------------------------------------------------------------- #
 class PointwiseConvFunction(torch.autograd.Function):
-    """y = act(conv1x1(x) * scale + shift (+ res)) on channels_last bf16 tensors as ONE kernel (adil_pw_conv_fwd: the
+    """y = act(conv1x1(x') * scale + shift (+ res)) on channels_last bf16 tensors as ONE kernel (adil_pw_conv_fwd: the
     GEMM with the epilogue applied to its accumulators), and its input gradient as ONE kernel (adil_pw_conv_bwd: the
     epilogue backward applied to the GEMM operand on its way into LDS).
+    `pre=(pscale, pshift)`: x is the RAW output of the previous (library) convolution and x' = relu(x*pscale+pshift)
+    is formed inside the kernels — that layer's BatchNorm + ReLU makes no HBM pass of its own, forward or backward —
+    otherwise x' = x.
     With `twin=True` the forward returns the result twice (same storage): a residual block hands one to its main
     path and one to its skip path, so that the two gradients arrive here separately and are summed inside the
     backward kernel instead of by an autograd add kernel."""
 
     @staticmethod
-    def forward(ctx, x, res, w2d, wt2d, scale, shift, relu, twin):
+    def forward(ctx, x, res, w2d, wt2d, scale, shift, relu, twin, pscale, pshift):
         lib = _lib.load()
         ctx.set_materialize_grads(False)
         b, cin, h, w = x.shape
@@ -390,8 +393,8 @@ class PointwiseConvFunction(torch.autograd.Function):
                 r2 = r2.contiguous()
         y = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device)
         _lib.check(lib.adil_pw_conv_fwd(_ptr(x2), _ptr(w2d), _ptr(scale), _ptr(shift), _ptr(r2), _ptr(y), b * h * w, cin, cout,
-                                        int(relu), _stream()), "adil_pw_conv_fwd")
-        ctx.save_for_backward(y if relu else None, scale, wt2d)
+                                        int(relu), _ptr(pscale), _ptr(pshift), _stream()), "adil_pw_conv_fwd")
+        ctx.save_for_backward(y if relu else None, scale, wt2d, x2 if pscale is not None else None, pscale, pshift)
         ctx.meta = (bool(relu), res is not None, cin)
         out = y.permute(0, 3, 1, 2)
         if twin:
@@ -401,12 +404,12 @@ class PointwiseConvFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, g_twin=None):
         lib = _lib.load()
-        y, scale, wt2d = ctx.saved_tensors
+        y, scale, wt2d, xin, pscale, pshift = ctx.saved_tensors
         relu, has_res, cin = ctx.meta
         if g is None:
             g, g_twin = g_twin, None
         if g is None:
-            return (None,) * 8
+            return (None,) * 10
 
         def nhwc(t):
             t2 = t.permute(0, 2, 3, 1)
@@ -418,13 +421,15 @@ class PointwiseConvFunction(torch.autograd.Function):
         gx = torch.empty((b, h, w, cin), dtype=torch.bfloat16, device=g2.device)
         gres = torch.empty_like(g2) if has_res else None
         _lib.check(lib.adil_pw_conv_bwd(_ptr(g2), _ptr(gt), _ptr(y), _ptr(scale), _ptr(wt2d), _ptr(gx), _ptr(gres), b * h * w,
-                                        cin, cout, int(relu), _stream()), "adil_pw_conv_bwd")
-        return (gx.permute(0, 3, 1, 2), gres.permute(0, 3, 1, 2) if has_res else None) + (None,) * 6
+                                        cin, cout, int(relu), _ptr(xin), _ptr(pscale), _ptr(pshift), _stream()),
+                   "adil_pw_conv_bwd")
+        return (gx.permute(0, 3, 1, 2), gres.permute(0, 3, 1, 2) if has_res else None) + (None,) * 8
 
 
 def pointwise_conv_affine(x: Tensor, w2d: Tensor, wt2d: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = None,
-                          relu: bool = True, twin: bool = False):
-    return PointwiseConvFunction.apply(x, res, w2d, wt2d, scale, shift, relu, twin)
+                          relu: bool = True, twin: bool = False, pre: Optional[Tuple[Tensor, Tensor]] = None):
+    pscale, pshift = pre if pre is not None else (None, None)
+    return PointwiseConvFunction.apply(x, res, w2d, wt2d, scale, shift, relu, twin, pscale, pshift)
 
 
 # --------------------------------------------------------------------------- #

@@ -419,14 +419,17 @@ class _ConvAffine(nn.Module):
         return (self.pointwise and x.is_cuda and x.dtype == torch.bfloat16 and self.conv.in_channels % 64 == 0
                 and self.conv.out_channels % 64 == 0 and self.conv.out_channels <= 2048)
 
-    def forward(self, x, res=None, twin=False):
-        """twin=True returns the result twice (see ops.PointwiseConvFunction): only valid when fused_pointwise(x)."""
+    def forward(self, x, res=None, twin=False, pre=None):
+        """twin=True returns the result twice; pre=(scale, shift) of the previous layer means x is that layer's RAW
+        convolution output (see ops.PointwiseConvFunction).  Both only with the fused kernels (fused_pointwise(x))."""
         from . import ops
         if self.fused_pointwise(x):
             w2d = self.conv.weight.reshape(self.conv.out_channels, self.conv.in_channels)
             if w2d.is_contiguous():                                      # (Cout, Cin): true for either memory format
                 return ops.pointwise_conv_affine(x, w2d, self.wt2d, self.scale, self.shift, res=res, relu=self.relu,
-                                                 twin=twin)
+                                                 twin=twin, pre=pre)
+        if pre is not None:
+            raise RuntimeError("pre= needs the fused pointwise kernels")
         y = ops.affine_act(self._conv(x), self.scale.float(), self.shift.float(), res=res, relu=self.relu)
         return (y, y) if twin else y
 
@@ -450,7 +453,13 @@ class _FusedResBlock(nn.Module):
         idt = xs if self.down is None else self.down(xs)
         out = self.c1(xm)
         if self.bottleneck:
-            return self.c3(self.c2(out), res=idt, twin=True)
+            raw = self.c2.conv(out)                                      # 3x3 convolution (library), no epilogue pass:
+            if (self.c2.relu and self.c3.fused_pointwise(raw) and self.c3.conv.in_channels <= 512
+                    and raw.is_contiguous(memory_format=torch.channels_last)):
+                return self.c3(raw, res=idt, twin=True, pre=(self.c2.scale, self.c2.shift))   # its bn2+ReLU runs inside c3
+            from . import ops
+            out = ops.affine_act(raw, self.c2.scale.float(), self.c2.shift.float(), relu=self.c2.relu)
+            return self.c3(out, res=idt, twin=True)
         return self.c2(out, res=idt)
 
 

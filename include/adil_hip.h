@@ -164,15 +164,20 @@ int adil_stem_conv_bwd(const void* gy, const void* w_bwd, float inv_std0, float 
 
 /* Pointwise (1x1, stride 1) convolution of the frozen network on channels_last storage, with the eval-BatchNorm /
  * residual / ReLU epilogue applied to the accumulators (bf16 in/out, fp32 accumulate):
- *     y[M][N] = act( (x[M][K] . w[N][K]^T) * scale[n] + shift[n] (+ res[M][N]) ),  M = B*H*W, K = Cin, N = Cout
- * K % 64 == 0, N % 64 == 0; res may be NULL; relu = 0/1. */
+ *     y[M][N] = act( (x'[M][K] . w[N][K]^T) * scale[n] + shift[n] (+ res[M][N]) ),  M = B*H*W, K = Cin, N = Cout
+ * K % 64 == 0, N % 64 == 0; res may be NULL; relu = 0/1.
+ * Optional prologue (pscale, pshift both non-NULL, K <= 512): x is the RAW output of the previous convolution and
+ * x' = relu(x * pscale[k] + pshift[k]) is formed on the operand path (its BatchNorm + ReLU never makes an HBM pass);
+ * otherwise x' = x. */
 int adil_pw_conv_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res, void* y, int M,
-                     int K, int N, int relu, void* stream);
+                     int K, int N, int relu, const float* pscale, const float* pshift, void* stream);
 /* Input gradient of adil_pw_conv_fwd.  v = g (+ g2 if not NULL: the two gradients meeting at a residual join),
  * mask = [y > 0] if relu else 1:   gres[M][N] = v * mask (optional),   gx[M][K] = (v * mask * scale[n]) . w,
- * with the weight given transposed, wt[K][N].  N % 64 == 0, K % 64 == 0. */
+ * with the weight given transposed, wt[K][N].  N % 64 == 0, K % 64 == 0, N <= 2048.
+ * With the forward's prologue (xin = the raw x, pscale, pshift) the result is the gradient wrt xin:
+ *     gx *= [xin * pscale + pshift > 0] * pscale. */
 int adil_pw_conv_bwd(const void* g, const void* g2, const void* y, const float* scale, const void* wt, void* gx, void* gres,
-                     int M, int K, int N, int relu, void* stream);
+                     int M, int K, int N, int relu, const void* xin, const float* pscale, const float* pshift, void* stream);
 
 #ifdef __cplusplus
 }

@@ -137,9 +137,13 @@ def test_pointwise_conv_fused_epilogue(m, k, n, relu, has_res):
     shift = (torch.randn(n, generator=gen) * 0.3).to(DEV)
     res = torch.randn(m, n, generator=gen).bfloat16().to(DEV) if has_res else None
     y = torch.full((m + 3, n), 7.0, dtype=torch.bfloat16, device=DEV)
+    pre = None
+    if k <= 512 and has_res:                       # also exercise the fused prologue x' = relu(x * pscale + pshift)
+        pre = ((0.5 + torch.rand(k, generator=gen)).to(DEV), (torch.randn(k, generator=gen) * 0.3).to(DEV))
     assert lib.adil_pw_conv_fwd(o._ptr(x), o._ptr(w), o._ptr(scale), o._ptr(shift), o._ptr(res), o._ptr(y), m, k, n, int(relu),
-                                o._stream()) == 0
-    ref = (x.float() @ w.float().t()) * scale + shift
+                                o._ptr(pre[0] if pre else None), o._ptr(pre[1] if pre else None), o._stream()) == 0
+    xe = torch.relu(x.float() * pre[0] + pre[1]).bfloat16().float() if pre else x.float()
+    ref = (xe @ w.float().t()) * scale + shift
     if has_res:
         ref = ref + res.float()
     if relu:
@@ -166,8 +170,12 @@ def test_pointwise_conv_fused_backward(m, k, n, relu, has_res, has_g2):
     scale = (0.5 + torch.rand(n, generator=gen)).to(DEV)
     gx = torch.full((m + 2, k), 7.0, dtype=torch.bfloat16, device=DEV)
     gres = torch.full((m + 2, n), 7.0, dtype=torch.bfloat16, device=DEV) if has_res else None
+    xin, ps, pb = None, None, None
+    if has_g2:                                     # also exercise the fused epilogue gx *= [xin*ps+pb > 0] * ps
+        xin = torch.randn(m, k, generator=gen).bfloat16().to(DEV)
+        ps, pb = (0.5 + torch.rand(k, generator=gen)).to(DEV), (torch.randn(k, generator=gen) * 0.3).to(DEV)
     assert lib.adil_pw_conv_bwd(o._ptr(g), o._ptr(g2), o._ptr(y), o._ptr(scale), o._ptr(wt), o._ptr(gx), o._ptr(gres), m, k, n,
-                                int(relu), o._stream()) == 0
+                                int(relu), o._ptr(xin), o._ptr(ps), o._ptr(pb), o._stream()) == 0
     v = g.float() + (g2.float() if has_g2 else 0.0)
     if relu:
         v = v * (y > 0)
@@ -176,6 +184,8 @@ def test_pointwise_conv_fused_backward(m, k, n, relu, has_res, has_g2):
         assert bool((gres[m:] == 7.0).all())
     gz = (v.bfloat16().float() if has_res or True else v) * scale      # the kernel scales the fp32 value, rounds once
     ref = (v * scale).bfloat16().float() @ w.float()
+    if xin is not None:
+        ref = ref.bfloat16().float() * ((xin.float() * ps + pb) > 0) * ps     # the kernel rounds gx once before the epilogue
     err = (gx[:m].float() - ref).abs()
     assert bool((err <= 2 ** -6 * ref.abs() + 3e-2).all()), float(err.max())
     assert float(err.mean()) < 4e-3
