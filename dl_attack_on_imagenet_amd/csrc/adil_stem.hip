@@ -764,3 +764,196 @@ extern "C" int adil_pw_conv_fwd(const void* x, const void* w, const float* scale
     if (N % 128 == 0) return launch_pw_fwd<128, false>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, st);
     return launch_pw_fwd<64, false>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, st);
 }
+
+// =========================================================================================================== //
+// 3x3 / stride 1 / pad 1 convolution of the frozen ResNet (conv2 of every bottleneck), NHWC bf16, raw output:
+// its BatchNorm + ReLU live in the next pointwise kernel's prologue, so this kernel is a pure implicit GEMM
+//     Y[m][n] = sum_{tap, c} X[m + (kh-1)*W + (kw-1)][c] * Wp[n][tap][c]        (taps crossing an image edge masked)
+// and the input gradient is the same kernel on flipped / transposed weights.  Pixels are tiled LINEARLY (128
+// consecutive (n,h,w) indices, any H, W): the halo of a tile is the contiguous range [m0-W-1, m0+128+W+1), staged
+// once per 64-channel chunk; the fragment of a lane's pixel for tap (kh,kw) is the LDS row pl + kh*W + kw.
+// Per tap one weight tile (double buffered, next tile's global loads in flight), ONE barrier, 16 MFMAs per wave on
+// 64 px x 64 (32) channel wave tiles.  No zero-fill launch, no epilogue pass.
+// =========================================================================================================== //
+namespace {
+
+#define C3_BM 128
+#define C3_LS 72
+
+template <int BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv3x3_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_t* __restrict__ y, int M, int H, int W, int C, int N,
+    int MT, int NT) {
+    constexpr int CTW = BN / 64;                         // channel tiles per wave (waves: 2 along pixels x 2 along channels)
+    constexpr int WCH = BN * 8 / 256;                    // 16-byte chunks of a weight tile per thread
+    constexpr int OS = BN + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int NP = C3_BM + 2 * W + 2;                    // halo pixels
+    bf16_t* sx = reinterpret_cast<bf16_t*>(smem_raw);    // [NP][C3_LS]  (later: [128][OS] output transpose)
+    const int sx_elems = (NP * C3_LS > C3_BM * OS ? NP * C3_LS : C3_BM * OS);
+    bf16_t* sw = sx + ((sx_elems + 7) & ~7);             // [2][BN][C3_LS]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    const int wpx = w & 1, wch = w >> 1;
+    int mt, nt;
+    if ((MT & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        nt = j % NT;
+        mt = (j / NT) * 8 + xcd;
+    } else {
+        nt = blockIdx.x % NT;
+        mt = blockIdx.x / NT;
+    }
+    const int m0 = mt * C3_BM, n0 = nt * BN;
+    const int nci = C >> 6;
+
+    // this lane's two pixels and the validity of their 9 taps
+    int pl[2];
+    unsigned vmask[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        pl[p] = (wpx * 2 + p) * 32 + c;
+        const int m = m0 + pl[p];
+        const int ww = m % W, hh = (m / W) % H;
+        unsigned vm = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int kh = t / 3, kw = t - 3 * kh;
+            const bool ok = (m < M) && (hh + kh - 1 >= 0) && (hh + kh - 1 < H) && (ww + kw - 1 >= 0) && (ww + kw - 1 < W);
+            vm |= ok ? (1u << t) : 0u;
+        }
+        vmask[p] = vm;
+    }
+
+    u32x4 xr[8], wr[WCH];
+    auto load_x = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = tid + 256 * i, px = q >> 3, ch = q & 7;
+            int gm = m0 - W - 1 + (px < NP ? px : NP - 1);
+            gm = gm < 0 ? 0 : (gm >= M ? M - 1 : gm);
+            xr[i] = *reinterpret_cast<const u32x4*>(x + (size_t)gm * C + cc * 64 + ch * 8);
+        }
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = tid + 256 * i, px = q >> 3, ch = q & 7;
+            if (px < NP) *reinterpret_cast<u32x4*>(sx + px * C3_LS + ch * 8) = xr[i];
+        }
+    };
+    auto load_w = [&](int it) {                          // it = cc * 9 + tap
+        const int cc = it / 9, tap = it - 9 * cc;
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int q = tid + 256 * i, row = q >> 3, ch = q & 7;
+            wr[i] = *reinterpret_cast<const u32x4*>(wp + ((size_t)(n0 + row) * 9 + tap) * C + cc * 64 + ch * 8);
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int q = tid + 256 * i, row = q >> 3, ch = q & 7;
+            *reinterpret_cast<u32x4*>(sw + (buf * BN + row) * C3_LS + ch * 8) = wr[i];
+        }
+    };
+
+    f32x16 acc[2][CTW];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][ct][r] = 0.0f;
+
+    load_x(0);
+    load_w(0);
+    store_x();
+    store_w(0);
+    __syncthreads();
+    const int nit = nci * 9;
+    for (int it = 0; it < nit; ++it) {
+        const int buf = it & 1;
+        const int cc = it / 9, tap = it - 9 * cc;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        if (it + 1 < nit) load_w(it + 1);
+        if (tap == 4 && cc + 1 < nci) load_x(cc + 1);                 // next channel chunk's halo flies under taps 4..8
+        const bf16_t* bw = sw + (buf * BN + (wch * CTW) * 32 + c) * C3_LS + 8 * h;
+        const int shift = kh * W + kw;
+        const bool ok0 = (vmask[0] >> tap) & 1u, ok1 = (vmask[1] >> tap) & 1u;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 b0 = lds8(sx + (pl[0] + shift) * C3_LS + 16 * ks + 8 * h);
+            bf16x8 b1 = lds8(sx + (pl[1] + shift) * C3_LS + 16 * ks + 8 * h);
+            u32x4 z0 = __builtin_bit_cast(u32x4, b0), z1 = __builtin_bit_cast(u32x4, b1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { z0[j] = ok0 ? z0[j] : 0u; z1[j] = ok1 ? z1[j] : 0u; }
+            b0 = __builtin_bit_cast(bf16x8, z0);
+            b1 = __builtin_bit_cast(bf16x8, z1);
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) {
+                const bf16x8 a = lds8(bw + ct * 32 * C3_LS + 16 * ks);
+                mma16(acc[0][ct], a, b0);
+                mma16(acc[1][ct], a, b1);
+            }
+        }
+        if (it + 1 < nit) store_w(buf ^ 1);
+        if (tap == 8 && cc + 1 < nci) {                               // all waves are done with this halo after the barrier
+            __syncthreads();
+            store_x();
+        }
+        __syncthreads();
+    }
+    // epilogue: transpose through LDS (all waves share one [128][OS] tile), 16-byte NHWC stores
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u32x2 t;
+                t[0] = pack2_bf16(acc[p][ct][4 * q], acc[p][ct][4 * q + 1]);
+                t[1] = pack2_bf16(acc[p][ct][4 * q + 2], acc[p][ct][4 * q + 3]);
+                *reinterpret_cast<u32x2*>(sx + pl[p] * OS + (wch * CTW + ct) * 32 + 8 * q + 4 * h) = t;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int CPP = BN / 8;
+#pragma unroll
+    for (int i = 0; i < C3_BM * CPP / 256; ++i) {
+        const int id = tid + 256 * i, px = id / CPP, ch = id - px * CPP;
+        const int mm = m0 + px;
+        if (mm < M) *reinterpret_cast<u32x4*>(y + (size_t)mm * N + n0 + ch * 8) = *reinterpret_cast<const u32x4*>(sx + px * OS + ch * 8);
+    }
+}
+
+template <int BN>
+int launch_conv3x3(const void* x, const void* wp, void* y, int M, int H, int W, int C, int N, hipStream_t st) {
+    const int MT = (M + C3_BM - 1) / C3_BM, NT = N / BN;
+    const int NP = C3_BM + 2 * W + 2;
+    size_t sx_elems = (size_t)NP * C3_LS;
+    if (sx_elems < (size_t)C3_BM * (BN + 8)) sx_elems = (size_t)C3_BM * (BN + 8);
+    sx_elems = (sx_elems + 7) & ~(size_t)7;
+    const size_t lds = (sx_elems + (size_t)2 * BN * C3_LS) * sizeof(bf16_t);
+    if (lds > 160 * 1024) return ADIL_EINVAL;
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(conv3x3_kernel<BN>, dim3((unsigned)(MT * NT)), dim3(256), lds, st, (const bf16_t*)x,
+                       (const bf16_t*)wp, (bf16_t*)y, M, H, W, C, N, MT, NT);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int adil_conv3x3(const void* x, const void* wp, void* y, int B, int H, int W, int C, int N, void* stream) {
+    ADIL_ENTER();
+    if (!x || !wp || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || (C % 64) || (N % 64) || W > 256) return ADIL_EINVAL;
+    const long long M = (long long)B * H * W;
+    if (M > 0x7fffffffLL) return ADIL_EINVAL;
+    if (N % 128 == 0) return launch_conv3x3<128>(x, wp, y, (int)M, H, W, C, N, (hipStream_t)stream);
+    return launch_conv3x3<64>(x, wp, y, (int)M, H, W, C, N, (hipStream_t)stream);
+}

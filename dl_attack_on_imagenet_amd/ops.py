@@ -433,6 +433,55 @@ def pointwise_conv_affine(x: Tensor, w2d: Tensor, wt2d: Tensor, scale: Tensor, s
 
 
 # --------------------------------------------------------------------------- #
+def pack_conv3x3_weights(weight: Tensor) -> Tuple[Tensor, Tensor]:
+    """(N,C,3,3) conv weight -> the two bf16 layouts of adil_conv3x3 (include/adil_hip.h), both 2-D:
+    forward [N][9*C] (w[n][c][kh][kw] at [n][kh*3+kw][c]) and input gradient [C][9*N] (taps flipped, channels swapped)."""
+    n, c, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError(f"expected a 3x3 convolution weight, got {tuple(weight.shape)}")
+    w = weight.detach().float()
+    fwd = w.permute(0, 2, 3, 1).reshape(n, 9 * c).to(torch.bfloat16).contiguous()
+    bwd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(c, 9 * n).to(torch.bfloat16).contiguous()
+    return fwd, bwd
+
+
+class Conv3x3Function(torch.autograd.Function):
+    """3x3 / stride 1 / pad 1 convolution on channels_last bf16 tensors (adil_conv3x3), raw output; the input gradient
+    is the same kernel on the flipped / transposed weights.  No weight gradient: the network is frozen."""
+
+    @staticmethod
+    def forward(ctx, x, wp_fwd, wp_bwd):
+        lib = _lib.load()
+        b, c, h, w = x.shape
+        n = wp_fwd.shape[0]
+        x2 = x.permute(0, 2, 3, 1)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        y = torch.empty((b, h, w, n), dtype=torch.bfloat16, device=x.device)
+        _lib.check(lib.adil_conv3x3(_ptr(x2), _ptr(wp_fwd), _ptr(y), b, h, w, c, n, _stream()), "adil_conv3x3")
+        ctx.save_for_backward(wp_bwd)
+        ctx.meta = (c,)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (wp_bwd,) = ctx.saved_tensors
+        (c,) = ctx.meta
+        g2 = g.permute(0, 2, 3, 1)
+        if not (g2.is_contiguous() and g2.dtype == torch.bfloat16):
+            g2 = g2.to(torch.bfloat16).contiguous()
+        b, h, w, n = g2.shape
+        gx = torch.empty((b, h, w, c), dtype=torch.bfloat16, device=g2.device)
+        _lib.check(lib.adil_conv3x3(_ptr(g2), _ptr(wp_bwd), _ptr(gx), b, h, w, n, c, _stream()), "adil_conv3x3")
+        return gx.permute(0, 3, 1, 2), None, None
+
+
+def conv3x3(x: Tensor, wp_fwd: Tensor, wp_bwd: Tensor) -> Tensor:
+    return Conv3x3Function.apply(x, wp_fwd, wp_bwd)
+
+
+# --------------------------------------------------------------------------- #
 def pack_stem_weights(weight: Tensor) -> Tuple[Tensor, Tensor]:
     """(64,3,7,7) conv weight -> the two bf16 layouts of include/adil_hip.h: w_fwd [64][7][8][4], w_bwd [4][49][64]."""
     if tuple(weight.shape) != (64, 3, 7, 7):

@@ -404,6 +404,21 @@ class _ConvAffine(nn.Module):
                           and conv.groups == 1 and conv.bias is None)
         if self.pointwise:      # (Cin, Cout) copy for the input-gradient kernel; 2-D, so channels_last leaves it alone
             self.register_buffer('wt2d', conv.weight.detach().reshape(conv.out_channels, conv.in_channels).t().contiguous())
+        self.dense3x3 = (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+                         and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+                         and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0)
+        if self.dense3x3:
+            from . import ops
+            wp_fwd, wp_bwd = ops.pack_conv3x3_weights(conv.weight)
+            self.register_buffer('wp_fwd', wp_fwd)
+            self.register_buffer('wp_bwd', wp_bwd)
+
+    def raw_conv(self, x):
+        """The convolution alone (no BatchNorm / ReLU): the hand-written 3x3 kernel where it applies, else the library."""
+        if self.dense3x3 and x.is_cuda and x.dtype == torch.bfloat16:
+            from . import ops
+            return ops.conv3x3(x, self.wp_fwd, self.wp_bwd)
+        return self.conv(x)
 
     def _conv(self, x):
         if self.pointwise and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last):
@@ -413,7 +428,7 @@ class _ConvAffine(nn.Module):
             wt = self.conv.weight.reshape(self.conv.out_channels, cin).t()            # (Cin, Cout) view
             y2 = torch.mm(x.permute(0, 2, 3, 1).reshape(b * h * w, cin), wt)
             return y2.reshape(b, h, w, -1).permute(0, 3, 1, 2)                         # channels_last storage
-        return self.conv(x)
+        return self.raw_conv(x)
 
     def fused_pointwise(self, x) -> bool:
         return (self.pointwise and x.is_cuda and x.dtype == torch.bfloat16 and self.conv.in_channels % 64 == 0
@@ -453,7 +468,7 @@ class _FusedResBlock(nn.Module):
         idt = xs if self.down is None else self.down(xs)
         out = self.c1(xm)
         if self.bottleneck:
-            raw = self.c2.conv(out)                                      # 3x3 convolution (library), no epilogue pass:
+            raw = self.c2.raw_conv(out)                                  # 3x3 convolution, no epilogue pass:
             if (self.c2.relu and self.c3.fused_pointwise(raw) and self.c3.conv.in_channels <= 512
                     and raw.is_contiguous(memory_format=torch.channels_last)):
                 return self.c3(raw, res=idt, twin=True, pre=(self.c2.scale, self.c2.shift))   # its bn2+ReLU runs inside c3

@@ -214,3 +214,38 @@ def test_fused_resnet50_gradient_matches_fp32():
     assert c1 >= c0 - 0.02, (c0, c1)
     n0, n1, nr = float(g0.float().norm()), float(g1.float().norm()), float(gr.norm())
     assert abs(n1 - nr) <= 2.0 * abs(n0 - nr) + 0.05 * nr, (n0, n1, nr)
+
+
+def _pack3x3(w):
+    """(N,C,3,3) -> forward layout [N][9][C] and input-gradient layout [C][9][N] (taps flipped), bf16."""
+    n, c = w.shape[:2]
+    fwd = w.permute(0, 2, 3, 1).reshape(n, 9, c).contiguous().bfloat16()
+    bwd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(c, 9, n).contiguous().bfloat16()
+    return fwd, bwd
+
+
+@pytest.mark.parametrize("b,h,w_,c,n", [(2, 14, 14, 64, 64), (1, 7, 7, 128, 128), (2, 56, 56, 64, 64), (1, 28, 28, 128, 128),
+                                        (3, 5, 9, 64, 128), (2, 14, 14, 256, 256), (1, 3, 3, 192, 64)])
+def test_conv3x3_forward_and_input_gradient(b, h, w_, c, n):
+    """adil_conv3x3 against torch's fp32 conv2d (same bf16 operands), forward and (with the flipped/transposed
+    packing) input gradient; ragged pixel counts, image edges and image-to-image boundaries included."""
+    o = ops()
+    lib = __import__("dl_attack_on_imagenet_amd._lib", fromlist=["x"]).load()
+    gen = torch.Generator().manual_seed(b * h * w_ + c + n)
+    x = torch.randn(b, h, w_, c, generator=gen).bfloat16().to(DEV)
+    wt = (torch.randn(n, c, 3, 3, generator=gen) / (9 * c) ** 0.5).bfloat16().float().to(DEV)
+    wf, wb = _pack3x3(wt)
+    y = torch.full((b * h * w_ + 5, n), 7.0, dtype=torch.bfloat16, device=DEV)
+    assert lib.adil_conv3x3(o._ptr(x), o._ptr(wf), o._ptr(y), b, h, w_, c, n, o._stream()) == 0
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt, padding=1).permute(0, 2, 3, 1).reshape(-1, n)
+    err = (y[:b * h * w_].float() - ref).abs()
+    assert bool((err <= 2 ** -7 * ref.abs() + 2e-3).all()), float(err.max())
+    assert bool((y[b * h * w_:] == 7.0).all())
+    g = torch.randn(b, h, w_, n, generator=gen).bfloat16().to(DEV)
+    gx = torch.empty(b * h * w_, c, dtype=torch.bfloat16, device=DEV)
+    assert lib.adil_conv3x3(o._ptr(g), o._ptr(wb), o._ptr(gx), b, h, w_, n, c, o._stream()) == 0
+    xin = torch.zeros(b, c, h, w_, device=DEV, requires_grad=True)
+    F.conv2d(xin, wt, padding=1).backward(g.float().permute(0, 3, 1, 2))
+    gref = xin.grad.permute(0, 2, 3, 1).reshape(-1, c)
+    gerr = (gx.float() - gref).abs()
+    assert bool((gerr <= 2 ** -7 * gref.abs() + 2e-3).all()), float(gerr.max())
