@@ -29,6 +29,13 @@ __device__ __forceinline__ void mma16(f32x16& acc, const bf16x8& a, const bf16x8
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 }
 __device__ __forceinline__ void lds_sync() { __syncthreads(); }
+// Workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() carries a fence that hipcc
+// lowers to s_waitcnt vmcnt(0), which drains every prefetched tile at every barrier (DESIGN.md finding 3a).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 struct StemNorm { float mean[3]; float inv_std[3]; };
 
@@ -515,7 +522,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRO && BN =
     for (int it = 0; it < nk; ++it) {
         store_tiles(it);
         if (it + 1 < nk) load_tiles(it + 1);
-        __syncthreads();
+        lds_barrier();
         const bf16_t* bx = sx + (w * 32 + c) * PW_LS + 8 * h;
         const bf16_t* bw = sw + c * PW_LS + 8 * h;
 #pragma unroll
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRO && BN =
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) mma16(acc[ct], lds8(bw + ct * 32 * PW_LS + 16 * ks), b);
         }
-        __syncthreads();
+        lds_barrier();
     }
     // epilogue on the accumulators: lane = pixel m, register quad q of tile ct = channels n0 + 32ct + 8q + 4h .. +3
     bf16_t* so = reinterpret_cast<bf16_t*>(smem_raw) + w * 32 * OS;     // the tile buffers are idle now
@@ -654,7 +661,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BO == 128 ?
     for (int it = 0; it < nn; ++it) {
         store_tiles(it);
         if (it + 1 < nn) load_tiles(it + 1);
-        __syncthreads();
+        lds_barrier();
         const bf16_t* bx = sx + (w * 32 + c) * PW_LS + 8 * h;
         const bf16_t* bw = sw + c * PW_LS + 8 * h;
 #pragma unroll
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BO == 128 ?
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) mma16(acc[ct], lds8(bw + ct * 32 * PW_LS + 16 * ks), b);
         }
-        __syncthreads();
+        lds_barrier();
     }
     bf16_t* so = reinterpret_cast<bf16_t*>(smem_raw) + w * 32 * OS;
 #pragma unroll
@@ -824,8 +831,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         vmask[p] = vm;
     }
 
-    u32x4 xr[8], wr[WCH];
-    auto load_x = [&](int cc) {
+    u32x4 xr[8], wr[3][WCH];                           // weight tiles are requested THREE taps ahead (an L2 round trip
+    auto load_x = [&](int cc) {                          // is ~5x the 16 MFMAs of one tap)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int q = tid + 256 * i, px = q >> 3, ch = q & 7;
@@ -841,19 +848,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             if (px < NP) *reinterpret_cast<u32x4*>(sx + px * C3_LS + ch * 8) = xr[i];
         }
     };
-    auto load_w = [&](int it) {                          // it = cc * 9 + tap
-        const int cc = it / 9, tap = it - 9 * cc;
+    const int nit = nci * 9;
+    auto load_w = [&](int it, u32x4 (&r)[WCH]) {         // it = cc * 9 + tap (clamped: the surplus loads are never stored)
+        const int itc = it < nit ? it : nit - 1;
+        const int cc = itc / 9, tap = itc - 9 * cc;
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
             const int q = tid + 256 * i, row = q >> 3, ch = q & 7;
-            wr[i] = *reinterpret_cast<const u32x4*>(wp + ((size_t)(n0 + row) * 9 + tap) * C + cc * 64 + ch * 8);
+            r[i] = *reinterpret_cast<const u32x4*>(wp + ((size_t)(n0 + row) * 9 + tap) * C + cc * 64 + ch * 8);
         }
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](int buf, const u32x4 (&r)[WCH]) {
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
             const int q = tid + 256 * i, row = q >> 3, ch = q & 7;
-            *reinterpret_cast<u32x4*>(sw + (buf * BN + row) * C3_LS + ch * 8) = wr[i];
+            *reinterpret_cast<u32x4*>(sw + (buf * BN + row) * C3_LS + ch * 8) = r[i];
         }
     };
 
@@ -865,17 +874,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][ct][r] = 0.0f;
 
-    load_x(0);
-    load_w(0);
-    store_x();
-    store_w(0);
-    __syncthreads();
-    const int nit = nci * 9;
-    for (int it = 0; it < nit; ++it) {
+    auto tap_body = [&](int it, u32x4 (&rfree)[WCH], const u32x4 (&rnext)[WCH]) {
+        // on entry: sw[it & 1] holds tile `it`, rnext holds tile it+1, the third register set holds tile it+2 (in
+        // flight), rfree's tile is already in LDS
         const int buf = it & 1;
         const int cc = it / 9, tap = it - 9 * cc;
         const int kh = tap / 3, kw = tap - 3 * kh;
-        if (it + 1 < nit) load_w(it + 1);
+        load_w(it + 3, rfree);
         if (tap == 4 && cc + 1 < nci) load_x(cc + 1);                 // next channel chunk's halo flies under taps 4..8
         const bf16_t* bw = sw + (buf * BN + (wch * CTW) * 32 + c) * C3_LS + 8 * h;
         const int shift = kh * W + kw;
@@ -896,12 +901,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
                 mma16(acc[1][ct], a, b1);
             }
         }
-        if (it + 1 < nit) store_w(buf ^ 1);
+        if (it + 1 < nit) store_w(buf ^ 1, rnext);
         if (tap == 8 && cc + 1 < nci) {                               // all waves are done with this halo after the barrier
-            __syncthreads();
+            lds_barrier();
             store_x();
         }
-        __syncthreads();
+        lds_barrier();
+    };
+
+    load_x(0);
+    load_w(0, wr[0]);
+    load_w(1, wr[1]);
+    load_w(2, wr[2]);
+    store_x();
+    store_w(0, wr[0]);
+    __syncthreads();
+    for (int it = 0; it < nit; it += 3) {                             // nit = 9 * nci: a multiple of 3
+        tap_body(it, wr[0], wr[1]);
+        tap_body(it + 1, wr[1], wr[2]);
+        tap_body(it + 2, wr[2], wr[0]);
     }
     // epilogue: transpose through LDS (all waves share one [128][OS] tile), 16-byte NHWC stores
 #pragma unroll

@@ -7,7 +7,7 @@ idx = [i for i, r in enumerate(rows) if 'synth_mfma_kernel' in r['Kernel_Name']]
 def short(n):
     n = n.strip('"')
     for key in ('stem_conv_fwd_kernel', 'stem_conv_bwd_kernel', 'stem_pool_bwd_kernel', 'maxpool_fwd_kernel',
-                'pw_conv_fwd_kernel', 'pw_conv_bwd_kernel'):
+                'pw_conv_fwd_kernel', 'pw_conv_bwd_kernel', 'conv3x3_kernel'):
         if key in n: return key
     if n.startswith('Cijk_') or 'Cijk_' in n: return 'hipBLASLt GEMM (Cijk_*)'
     for key, lab in (('batch_norm', 'batch_norm'), ('conv_bwd_data', 'conv_bwd_data'), ('igemm_bwd', 'conv_bwd_data'), ('conv_fwd', 'conv_fwd'),
