@@ -222,7 +222,8 @@ def main():
                    "classifier": f"random-init {args.model}, frozen, eval; channels_last={args.channels_last}, "
                                  f"bn_act_epilogue_fused={args.fuse_bn_act}, bn_folded={args.fold_bn}, "
                                  f"first_conv_cin_padded_to={args.pad_cin} (unused with stem kernels), stem_kernels={args.fuse_stem}, "
-                                 f"pointwise_convs=fused GEMM+epilogue kernels (fwd and input gradient)",
+                                 f"pointwise_convs=fused GEMM+epilogue kernels (fwd and input gradient), "
+                                 f"stride1_3x3_convs=adil_conv3x3",
                    "global_batch": world * B, "atoms": K, "inner_iters": args.steps,
                    "parallelism": f"dp{world}: images+codes sharded, D replicated, 1 all-reduce(grad_d)/step",
                    "train_fooling_rate_last_step": fool_rate},
