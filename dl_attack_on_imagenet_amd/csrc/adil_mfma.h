@@ -1,0 +1,43 @@
+// adil_mfma.h — small device helpers shared by the frozen-classifier kernels (adil_stem.hip, adil_convs.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "adil_common.h"
+
+namespace {
+
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 lds8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void mma16(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void lds_sync() { __syncthreads(); }
+// Workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() carries a fence that hipcc
+// lowers to s_waitcnt vmcnt(0), which drains every prefetched tile at every barrier (DESIGN.md finding 3a).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ void unpack8(const u32x4& t, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(t[i] << 16);
+        f[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    u32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = pack2_bf16(f[2 * i], f[2 * i + 1]);
+    return t;
+}
+
+}  // namespace

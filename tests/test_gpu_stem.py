@@ -1,4 +1,4 @@
-"""GPU parity of the hand-written ResNet stem kernels (csrc/adil_stem.hip) against plain PyTorch fp32 references of
+"""GPU parity of the hand-written frozen-ResNet kernels (csrc/adil_stem.hip, csrc/adil_convs.hip) against plain PyTorch fp32 references of
 the same ops on the same (bf16-rounded) operands.  These kernels sit on either side of the ADiL hot path (they
 consume x_adv and produce dLoss/dx_adv); tolerances are bf16 output rounding (2^-8 relative)."""
 import numpy as np
