@@ -43,9 +43,9 @@ SIGNATURES = {
     "adil_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "adil_stem_pool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "adil_pw_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                 c_void_p, c_void_p, c_void_p]),
+                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "adil_pw_conv_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "adil_conv3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "adil_stem_conv_bwd": (c_int, [c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_int, c_int, c_int, c_int,
                                    c_void_p]),

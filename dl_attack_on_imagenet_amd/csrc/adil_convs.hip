@@ -34,7 +34,7 @@ template <int BN, bool PRO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRO && BN == 128 ? 2 : 3))) void pw_conv_fwd_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ wgt, const float* __restrict__ scale,
     const float* __restrict__ shift, const bf16_t* __restrict__ res, bf16_t* __restrict__ y, int M, int K, int N,
-    int relu, int MT, int NT, const float* __restrict__ pscale, const float* __restrict__ pshift) {
+    int relu, int MT, int NT, const float* __restrict__ pscale, const float* __restrict__ pshift, int sub_w, int sub_hw) {
     constexpr int CT = BN / 32;                          // channel tiles per wave
     constexpr int XCH = PW_BM * PW_BK / 8 / 256;         // 16-byte chunks of the X tile per thread (4)
     constexpr int WCH = BN * PW_BK / 8 / 256;            // ... of the W tile (4 or 2)
@@ -69,13 +69,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRO && BN =
         __syncthreads();
     }
 
+    // rows of X this thread stages (fixed over the K loop).  sub_w > 0: the convolution has stride 2 — output pixel
+    // m = (n, oh, ow) of an (OH = sub_hw / sub_w) x (OW = sub_w) grid reads input pixel (n, 2 oh, 2 ow) of the
+    // 2 OH x 2 OW tensor x points to (the stride-2 downsample convolutions gather, nothing is copied)
+    size_t xrow[XCH];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+        const int id = tid + 256 * i, row = id >> 3;
+        const int mm = (m0 + row < M) ? m0 + row : M - 1;
+        if (sub_w > 0) {
+            const int n = mm / sub_hw, r = mm - n * sub_hw, oh = r / sub_w, ow = r - oh * sub_w;
+            xrow[i] = (size_t)4 * n * sub_hw + (size_t)4 * oh * sub_w + 2 * ow;
+        } else {
+            xrow[i] = (size_t)mm;
+        }
+    }
     u32x4 xr[XCH], wr[WCH];
     auto load_tiles = [&](int kc) {
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
-            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-            const int mm = m0 + row;
-            xr[i] = *reinterpret_cast<const u32x4*>(x + (size_t)(mm < M ? mm : M - 1) * K + kc * PW_BK + ch * 8);
+            const int id = tid + 256 * i, ch = id & 7;
+            xr[i] = *reinterpret_cast<const u32x4*>(x + xrow[i] * K + kc * PW_BK + ch * 8);
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
@@ -179,12 +193,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRO && BN =
 // The epilogue backward is applied to the X-operand chunk on its way from registers to LDS (it would otherwise be a
 // separate kernel writing and re-reading an M x N tensor), and g2 lets the caller hand over the two gradients that
 // meet at a residual join without adding them first (autograd's add kernels were 3 ms of a 46 ms step).
-template <int BO>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BO == 128 ? 2 : 3))) void pw_conv_bwd_kernel(
+template <int BO, bool G3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BO == 128 || G3) ? 2 : 3))) void pw_conv_bwd_kernel(
     const bf16_t* __restrict__ g, const bf16_t* __restrict__ g2, const bf16_t* __restrict__ y,
     const float* __restrict__ scale, const bf16_t* __restrict__ wt, bf16_t* __restrict__ gx, bf16_t* __restrict__ gres,
     int M, int K, int N, int relu, int MT, int OT, const bf16_t* __restrict__ xin, const float* __restrict__ pscale,
-    const float* __restrict__ pshift) {
+    const float* __restrict__ pshift, const bf16_t* __restrict__ g3, int sub_w, int sub_hw) {
     constexpr int CT = BO / 32;
     constexpr int XCH = PW_BM * PW_BK / 8 / 256;         // 4
     constexpr int WCH = BO * PW_BK / 8 / 256;
@@ -209,7 +223,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BO == 128 ?
     for (int i = tid; i < N; i += 256) ssc[i] = scale[i];
     __syncthreads();
 
-    u32x4 gr[XCH], hr[XCH], yr[XCH], wr[WCH];
+    // G3: a third incoming gradient that lives on the stride-2 grid (it comes back from a stride-2 downsample
+    // convolution reading this layer's output): pixel (n, h, w) of the 2 OH x 2 OW grid receives g3[(n, h/2, w/2)] when
+    // h and w are even, nothing otherwise — the zero-upsampled tensor is never materialised.
+    size_t g3row[G3 ? XCH : 1];
+    float g3on[G3 ? XCH : 1];
+    if (G3) {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int id = tid + 256 * i, row = id >> 3;
+            const int mm = (m0 + row < M) ? m0 + row : M - 1;
+            const int hw4 = 4 * sub_hw, w2 = 2 * sub_w;
+            const int n = mm / hw4, r = mm - n * hw4, hh = r / w2, ww = r - hh * w2;
+            g3on[i] = ((hh | ww) & 1) ? 0.0f : 1.0f;
+            g3row[i] = (size_t)n * sub_hw + (size_t)(hh >> 1) * sub_w + (ww >> 1);
+        }
+    }
+    u32x4 gr[XCH], hr[XCH], yr[XCH], tr[G3 ? XCH : 1], wr[WCH];
     auto load_tiles = [&](int nc) {
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
@@ -219,6 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BO == 128 ?
             gr[i] = *reinterpret_cast<const u32x4*>(g + at);
             if (g2 != nullptr) hr[i] = *reinterpret_cast<const u32x4*>(g2 + at);
             if (relu) yr[i] = *reinterpret_cast<const u32x4*>(y + at);
+            if (G3) tr[i] = *reinterpret_cast<const u32x4*>(g3 + g3row[i] * N + nc * PW_BK + ch * 8);   // always a valid address
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
@@ -236,6 +267,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BO == 128 ?
                 unpack8(hr[i], t8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += t8[j];
+            }
+            if (G3) {
+                unpack8(tr[i], t8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += t8[j] * g3on[i];
             }
             if (relu) {
                 unpack8(yr[i], t8);
@@ -316,23 +352,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BO == 128 ?
     }
 }
 
-template <int BO>
+template <int BO, bool G3>
 int launch_pw_bwd(const void* g, const void* g2, const void* y, const float* scale, const void* wt, void* gx, void* gres,
-                  int M, int K, int N, int relu, const void* xin, const float* pscale, const float* pshift, hipStream_t st) {
+                  int M, int K, int N, int relu, const void* xin, const float* pscale, const float* pshift, const void* g3,
+                  int sub_w, int sub_hw, hipStream_t st) {
     const int MT = (M + PW_BM - 1) / PW_BM, OT = K / BO;
     const size_t tiles = (size_t)(PW_BM + BO) * PW_LS * sizeof(bf16_t);
     const size_t outb = (size_t)4 * 32 * (BO + 8) * sizeof(bf16_t);
     const size_t lds = tiles > outb ? tiles : outb;
-    hipLaunchKernelGGL(pw_conv_bwd_kernel<BO>, dim3((unsigned)(MT * OT)), dim3(256), lds, st, (const bf16_t*)g,
+    hipLaunchKernelGGL((pw_conv_bwd_kernel<BO, G3>), dim3((unsigned)(MT * OT)), dim3(256), lds, st, (const bf16_t*)g,
                        (const bf16_t*)g2, (const bf16_t*)y, scale, (const bf16_t*)wt, (bf16_t*)gx, (bf16_t*)gres, M, K, N,
-                       relu, MT, OT, (const bf16_t*)xin, pscale, pshift);
+                       relu, MT, OT, (const bf16_t*)xin, pscale, pshift, (const bf16_t*)g3, sub_w, sub_hw);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
 
 template <int BN, bool PRO>
 int launch_pw_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res, void* y, int M,
-                  int K, int N, int relu, const float* pscale, const float* pshift, hipStream_t st) {
+                  int K, int N, int relu, const float* pscale, const float* pshift, int sub_w, int sub_hw, hipStream_t st) {
     const int MT = (M + PW_BM - 1) / PW_BM, NT = N / BN;
     const size_t tiles = (size_t)(PW_BM + BN) * PW_LS * sizeof(bf16_t);
     const size_t outb = (size_t)4 * 32 * (BN + 8) * sizeof(bf16_t);
@@ -343,7 +380,7 @@ int launch_pw_fwd(const void* x, const void* w, const float* scale, const float*
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL((pw_conv_fwd_kernel<BN, PRO>), dim3((unsigned)(MT * NT)), dim3(256), lds, st, (const bf16_t*)x,
-                       (const bf16_t*)w, scale, shift, (const bf16_t*)res, (bf16_t*)y, M, K, N, relu, MT, NT, pscale, pshift);
+                       (const bf16_t*)w, scale, shift, (const bf16_t*)res, (bf16_t*)y, M, K, N, relu, MT, NT, pscale, pshift, sub_w, sub_hw);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
@@ -352,29 +389,38 @@ int launch_pw_fwd(const void* x, const void* w, const float* scale, const float*
 
 extern "C" int adil_pw_conv_bwd(const void* g, const void* g2, const void* y, const float* scale, const void* wt, void* gx,
                                 void* gres, int M, int K, int N, int relu, const void* xin, const float* pscale,
-                                const float* pshift, void* stream) {
+                                const float* pshift, const void* g3, int sub_w, int sub_hw, void* stream) {
     ADIL_ENTER();
     if (!g || !scale || !wt || !gx || (relu && !y) || M <= 0 || K <= 0 || N <= 0 || (N % PW_BK) || (K % 64) || N > 2048)
         return ADIL_EINVAL;
     if (xin && (!pscale || !pshift)) return ADIL_EINVAL;
+    if (g3 && (sub_w <= 0 || sub_hw <= 0 || sub_hw % sub_w || M % (4 * sub_hw))) return ADIL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (K % 128 == 0) return launch_pw_bwd<128>(g, g2, y, scale, wt, gx, gres, M, K, N, relu, xin, pscale, pshift, st);
-    return launch_pw_bwd<64>(g, g2, y, scale, wt, gx, gres, M, K, N, relu, xin, pscale, pshift, st);
+    if (g3) {
+        if (K % 128 == 0)
+            return launch_pw_bwd<128, true>(g, g2, y, scale, wt, gx, gres, M, K, N, relu, xin, pscale, pshift, g3, sub_w, sub_hw, st);
+        return launch_pw_bwd<64, true>(g, g2, y, scale, wt, gx, gres, M, K, N, relu, xin, pscale, pshift, g3, sub_w, sub_hw, st);
+    }
+    if (K % 128 == 0)
+        return launch_pw_bwd<128, false>(g, g2, y, scale, wt, gx, gres, M, K, N, relu, xin, pscale, pshift, nullptr, 0, 0, st);
+    return launch_pw_bwd<64, false>(g, g2, y, scale, wt, gx, gres, M, K, N, relu, xin, pscale, pshift, nullptr, 0, 0, st);
 }
 
 extern "C" int adil_pw_conv_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res,
                                 void* y, int M, int K, int N, int relu, const float* pscale, const float* pshift,
-                                void* stream) {
+                                int sub_w, int sub_hw, void* stream) {
     ADIL_ENTER();
     if (!x || !w || !scale || !shift || !y || M <= 0 || K <= 0 || N <= 0 || (K % PW_BK) || (N % 64)) return ADIL_EINVAL;
     if ((pscale != nullptr) != (pshift != nullptr) || (pscale && K > PW_PK)) return ADIL_EINVAL;
+    if (sub_w < 0 || (sub_w > 0 && (sub_hw <= 0 || sub_hw % sub_w || M % sub_hw))) return ADIL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (pscale) {
-        if (N % 128 == 0) return launch_pw_fwd<128, true>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, st);
-        return launch_pw_fwd<64, true>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, st);
+        if (N % 128 == 0)
+            return launch_pw_fwd<128, true>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, sub_w, sub_hw, st);
+        return launch_pw_fwd<64, true>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, sub_w, sub_hw, st);
     }
-    if (N % 128 == 0) return launch_pw_fwd<128, false>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, st);
-    return launch_pw_fwd<64, false>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, st);
+    if (N % 128 == 0) return launch_pw_fwd<128, false>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, sub_w, sub_hw, st);
+    return launch_pw_fwd<64, false>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, sub_w, sub_hw, st);
 }
 
 // =========================================================================================================== //

@@ -373,19 +373,29 @@ class PointwiseConvFunction(torch.autograd.Function):
     `pre=(pscale, pshift)`: x is the RAW output of the previous (library) convolution and x' = relu(x*pscale+pshift)
     is formed inside the kernels — that layer's BatchNorm + ReLU makes no HBM pass of its own, forward or backward —
     otherwise x' = x.
-    With `twin=True` the forward returns the result twice (same storage): a residual block hands one to its main
-    path and one to its skip path, so that the two gradients arrive here separately and are summed inside the
-    backward kernel instead of by an autograd add kernel."""
+    `outputs` = 1: y.  2: (y, y) — a residual block hands one to its main path and one to its skip path, so that the two
+    gradients arrive here separately and are summed inside the backward kernel instead of by an autograd add kernel.
+    3: (y, y, y[:, :, ::2, ::2]) — the third is the (strided, uncopied) input of the next block's stride-2 downsample
+    convolution; its gradient comes back on the stride-2 grid and is added in the kernel, never zero-upsampled.
+    `stride2=True`: x is such a [:, :, ::2, ::2] view (offset 0) of a channels_last tensor; the kernel gathers."""
 
     @staticmethod
-    def forward(ctx, x, res, w2d, wt2d, scale, shift, relu, twin, pscale, pshift):
+    def forward(ctx, x, res, w2d, wt2d, scale, shift, relu, outputs, pscale, pshift, stride2):
         lib = _lib.load()
         ctx.set_materialize_grads(False)
-        b, cin, h, w = x.shape
+        b, cin, h, w = x.shape                                            # h, w: OUTPUT grid (= input grid unless stride2)
         cout = w2d.shape[0]
-        x2 = x.permute(0, 2, 3, 1)
-        if not x2.is_contiguous():
-            x2 = x2.contiguous()
+        sub_w, sub_hw = 0, 0
+        if stride2:
+            full = (4 * h * w * cin, 1, 4 * w * cin, 2 * cin)             # strides of t[:, :, ::2, ::2], t channels_last
+            if tuple(x.stride()) == full:
+                x2, sub_w, sub_hw = x, w, h * w                           # read in place through the gather
+            else:
+                x2 = x.permute(0, 2, 3, 1).contiguous()
+        else:
+            x2 = x.permute(0, 2, 3, 1)
+            if not x2.is_contiguous():
+                x2 = x2.contiguous()
         r2 = None
         if res is not None:
             r2 = res.permute(0, 2, 3, 1)
@@ -393,23 +403,29 @@ class PointwiseConvFunction(torch.autograd.Function):
                 r2 = r2.contiguous()
         y = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device)
         _lib.check(lib.adil_pw_conv_fwd(_ptr(x2), _ptr(w2d), _ptr(scale), _ptr(shift), _ptr(r2), _ptr(y), b * h * w, cin, cout,
-                                        int(relu), _ptr(pscale), _ptr(pshift), _stream()), "adil_pw_conv_fwd")
+                                        int(relu), _ptr(pscale), _ptr(pshift), sub_w, sub_hw, _stream()), "adil_pw_conv_fwd")
+        if pscale is not None and sub_w:
+            raise RuntimeError("prologue and stride-2 gather are not combined")
         ctx.save_for_backward(y if relu else None, scale, wt2d, x2 if pscale is not None else None, pscale, pshift)
         ctx.meta = (bool(relu), res is not None, cin)
         out = y.permute(0, 3, 1, 2)
-        if twin:
+        if outputs == 1:
+            return out
+        if outputs == 2:
             return out, out.view_as(out)
-        return out
+        return out, out.view_as(out), out[:, :, ::2, ::2]
 
     @staticmethod
-    def backward(ctx, g, g_twin=None):
+    def backward(ctx, g, g_twin=None, g_sub=None):
         lib = _lib.load()
         y, scale, wt2d, xin, pscale, pshift = ctx.saved_tensors
         relu, has_res, cin = ctx.meta
         if g is None:
             g, g_twin = g_twin, None
         if g is None:
-            return (None,) * 10
+            if g_sub is not None:
+                raise RuntimeError("a stride-2 gradient arrived without a full-resolution one")
+            return (None,) * 11
 
         def nhwc(t):
             t2 = t.permute(0, 2, 3, 1)
@@ -418,18 +434,25 @@ class PointwiseConvFunction(torch.autograd.Function):
         g2 = nhwc(g)
         gt = nhwc(g_twin) if g_twin is not None else None
         b, h, w, cout = g2.shape
+        g3, sub_w, sub_hw = None, 0, 0
+        if g_sub is not None:
+            g3 = nhwc(g_sub)
+            sub_w, sub_hw = g3.shape[2], g3.shape[1] * g3.shape[2]
+            if (h, w) != (2 * g3.shape[1], 2 * g3.shape[2]):
+                raise RuntimeError("stride-2 gradient does not match an even full-resolution grid")
         gx = torch.empty((b, h, w, cin), dtype=torch.bfloat16, device=g2.device)
         gres = torch.empty_like(g2) if has_res else None
         _lib.check(lib.adil_pw_conv_bwd(_ptr(g2), _ptr(gt), _ptr(y), _ptr(scale), _ptr(wt2d), _ptr(gx), _ptr(gres), b * h * w,
-                                        cin, cout, int(relu), _ptr(xin), _ptr(pscale), _ptr(pshift), _stream()),
-                   "adil_pw_conv_bwd")
-        return (gx.permute(0, 3, 1, 2), gres.permute(0, 3, 1, 2) if has_res else None) + (None,) * 8
+                                        cin, cout, int(relu), _ptr(xin), _ptr(pscale), _ptr(pshift), _ptr(g3), sub_w, sub_hw,
+                                        _stream()), "adil_pw_conv_bwd")
+        return (gx.permute(0, 3, 1, 2), gres.permute(0, 3, 1, 2) if has_res else None) + (None,) * 9
 
 
 def pointwise_conv_affine(x: Tensor, w2d: Tensor, wt2d: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = None,
-                          relu: bool = True, twin: bool = False, pre: Optional[Tuple[Tensor, Tensor]] = None):
+                          relu: bool = True, outputs: int = 1, pre: Optional[Tuple[Tensor, Tensor]] = None,
+                          stride2: bool = False):
     pscale, pshift = pre if pre is not None else (None, None)
-    return PointwiseConvFunction.apply(x, res, w2d, wt2d, scale, shift, relu, twin, pscale, pshift)
+    return PointwiseConvFunction.apply(x, res, w2d, wt2d, scale, shift, relu, outputs, pscale, pshift, stride2)
 
 
 # --------------------------------------------------------------------------- #

@@ -400,9 +400,10 @@ class _ConvAffine(nn.Module):
         self.register_buffer('scale', scale)
         self.register_buffer('shift', shift)
         # a 1x1 / stride-1 convolution of a channels_last tensor IS a row-major GEMM (B*H*W x Cin) @ (Cin x Cout)
-        self.pointwise = (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
-                          and conv.groups == 1 and conv.bias is None)
-        if self.pointwise:      # (Cin, Cout) copy for the input-gradient kernel; 2-D, so channels_last leaves it alone
+        one_by_one = (conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None)
+        self.pointwise = one_by_one and conv.stride == (1, 1)
+        self.pointwise_s2 = one_by_one and conv.stride == (2, 2)         # the ResNet downsample convolutions
+        if one_by_one:          # (Cin, Cout) copy for the input-gradient kernel; 2-D, so channels_last leaves it alone
             self.register_buffer('wt2d', conv.weight.detach().reshape(conv.out_channels, conv.in_channels).t().contiguous())
         self.dense3x3 = (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
                          and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
@@ -430,23 +431,30 @@ class _ConvAffine(nn.Module):
             return y2.reshape(b, h, w, -1).permute(0, 3, 1, 2)                         # channels_last storage
         return self.raw_conv(x)
 
-    def fused_pointwise(self, x) -> bool:
-        return (self.pointwise and x.is_cuda and x.dtype == torch.bfloat16 and self.conv.in_channels % 64 == 0
+    def _fusable(self, x) -> bool:
+        return (x.is_cuda and x.dtype == torch.bfloat16 and self.conv.in_channels % 64 == 0
                 and self.conv.out_channels % 64 == 0 and self.conv.out_channels <= 2048)
 
-    def forward(self, x, res=None, twin=False, pre=None):
-        """twin=True returns the result twice; pre=(scale, shift) of the previous layer means x is that layer's RAW
-        convolution output (see ops.PointwiseConvFunction).  Both only with the fused kernels (fused_pointwise(x))."""
+    def fused_pointwise(self, x) -> bool:
+        return self.pointwise and self._fusable(x)
+
+    def fused_pointwise_s2(self, x) -> bool:
+        return self.pointwise_s2 and self._fusable(x)
+
+    def forward(self, x, res=None, outputs=1, pre=None, strided_view=False):
+        """outputs = 2 / 3: the result twice (+ its [:, :, ::2, ::2] view); pre=(scale, shift) of the previous layer
+        means x is that layer's RAW convolution output; strided_view: x is a [:, :, ::2, ::2] view for a stride-2 1x1
+        convolution (see ops.PointwiseConvFunction).  All only with the fused kernels."""
         from . import ops
-        if self.fused_pointwise(x):
+        if self.fused_pointwise(x) or (strided_view and self.fused_pointwise_s2(x)):
             w2d = self.conv.weight.reshape(self.conv.out_channels, self.conv.in_channels)
             if w2d.is_contiguous():                                      # (Cout, Cin): true for either memory format
                 return ops.pointwise_conv_affine(x, w2d, self.wt2d, self.scale, self.shift, res=res, relu=self.relu,
-                                                 twin=twin, pre=pre)
-        if pre is not None:
-            raise RuntimeError("pre= needs the fused pointwise kernels")
+                                                 outputs=outputs, pre=pre, stride2=strided_view)
+        if pre is not None or strided_view:
+            raise RuntimeError("pre= / strided_view need the fused pointwise kernels")
         y = ops.affine_act(self._conv(x), self.scale.float(), self.shift.float(), res=res, relu=self.relu)
-        return (y, y) if twin else y
+        return y if outputs == 1 else ((y, y) if outputs == 2 else (y, y, y[:, :, ::2, ::2]))
 
 
 class _FusedResBlock(nn.Module):
@@ -460,21 +468,29 @@ class _FusedResBlock(nn.Module):
         else:
             self.c2 = _ConvAffine(block.conv2, block.bn2, True)          # + residual, then ReLU
         self.down = None if block.downsample is None else _ConvAffine(block.downsample[0], block.downsample[1], False)
+        self.emit_sub = False            # set by FusedResNet: the NEXT block has a stride-2 pointwise downsample
 
     def forward(self, x):
-        """x is a tensor or a (main, skip) pair of the same activation (see _ConvAffine.forward, twin=True): the pair
-        keeps the two gradients of the residual join apart until the producing kernel's backward adds them."""
-        xm, xs = x if isinstance(x, tuple) else (x, x)
-        idt = xs if self.down is None else self.down(xs)
+        """x is a tensor, a (main, skip) pair or a (main, skip, skip[:, :, ::2, ::2]) triple of the same activation (see
+        _ConvAffine.forward): the pair keeps the two gradients of the residual join apart until the producing kernel's
+        backward adds them; the third member feeds a stride-2 downsample convolution without a copy."""
+        xm, xs, xsub = (x + (None,))[:3] if isinstance(x, tuple) else (x, x, None)
+        if self.down is None:
+            idt = xs
+        elif xsub is not None and self.down.fused_pointwise_s2(xsub):
+            idt = self.down(xsub, strided_view=True)
+        else:
+            idt = self.down(xs)
         out = self.c1(xm)
         if self.bottleneck:
+            n_out = 3 if self.emit_sub else 2
             raw = self.c2.raw_conv(out)                                  # 3x3 convolution, no epilogue pass:
             if (self.c2.relu and self.c3.fused_pointwise(raw) and self.c3.conv.in_channels <= 512
                     and raw.is_contiguous(memory_format=torch.channels_last)):
-                return self.c3(raw, res=idt, twin=True, pre=(self.c2.scale, self.c2.shift))   # its bn2+ReLU runs inside c3
+                return self.c3(raw, res=idt, outputs=n_out, pre=(self.c2.scale, self.c2.shift))   # bn2+ReLU run inside c3
             from . import ops
             out = ops.affine_act(raw, self.c2.scale.float(), self.c2.shift.float(), relu=self.c2.relu)
-            return self.c3(out, res=idt, twin=True)
+            return self.c3(out, res=idt, outputs=n_out)
         return self.c2(out, res=idt)
 
 
@@ -519,6 +535,9 @@ class FusedResNet(nn.Module):
             self.maxpool = net.maxpool
         self.layers = nn.Sequential(*[_FusedResBlock(b) for layer in (net.layer1, net.layer2, net.layer3, net.layer4)
                                       for b in layer])
+        blocks = list(self.layers)
+        for cur, nxt in zip(blocks[:-1], blocks[1:]):
+            cur.emit_sub = bool(cur.bottleneck and nxt.down is not None and nxt.down.pointwise_s2)
         self.avgpool, self.fc = net.avgpool, net.fc
 
     def forward(self, x):

@@ -162,22 +162,28 @@ int adil_stem_pool_bwd(const void* g, const uint8_t* idx, const void* p, const f
 int adil_stem_conv_bwd(const void* gy, const void* w_bwd, float inv_std0, float inv_std1, float inv_std2, void* gx,
                        int gx_dtype, int B, int H, int W, void* stream);
 
-/* Pointwise (1x1, stride 1) convolution of the frozen network on channels_last storage, with the eval-BatchNorm /
- * residual / ReLU epilogue applied to the accumulators (bf16 in/out, fp32 accumulate):
- *     y[M][N] = act( (x'[M][K] . w[N][K]^T) * scale[n] + shift[n] (+ res[M][N]) ),  M = B*H*W, K = Cin, N = Cout
+/* Pointwise (1x1) convolution of the frozen network on channels_last storage, with the eval-BatchNorm / residual /
+ * ReLU epilogue applied to the accumulators (bf16 in/out, fp32 accumulate):
+ *     y[M][N] = act( (x'[M][K] . w[N][K]^T) * scale[n] + shift[n] (+ res[M][N]) ),  M = output pixels, K = Cin, N = Cout
  * K % 64 == 0, N % 64 == 0; res may be NULL; relu = 0/1.
+ * Stride 2 (the ResNet downsample convolutions): sub_w = OW > 0, sub_hw = OH*OW: output pixel (n,oh,ow) reads input
+ * pixel (n,2oh,2ow) of the B x 2OH x 2OW x K tensor x points to (gathered, nothing copied); sub_w = 0: stride 1.
  * Optional prologue (pscale, pshift both non-NULL, K <= 512): x is the RAW output of the previous convolution and
  * x' = relu(x * pscale[k] + pshift[k]) is formed on the operand path (its BatchNorm + ReLU never makes an HBM pass);
  * otherwise x' = x. */
 int adil_pw_conv_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res, void* y, int M,
-                     int K, int N, int relu, const float* pscale, const float* pshift, void* stream);
-/* Input gradient of adil_pw_conv_fwd.  v = g (+ g2 if not NULL: the two gradients meeting at a residual join),
- * mask = [y > 0] if relu else 1:   gres[M][N] = v * mask (optional),   gx[M][K] = (v * mask * scale[n]) . w,
- * with the weight given transposed, wt[K][N].  N % 64 == 0, K % 64 == 0, N <= 2048.
+                     int K, int N, int relu, const float* pscale, const float* pshift, int sub_w, int sub_hw, void* stream);
+/* Input gradient of adil_pw_conv_fwd (of the stride-1 form; a stride-2 layer calls it with M = its output pixels and
+ * gets the gradient on its own stride-2 grid).  v = g (+ g2) (+ up2(g3)), mask = [y > 0] if relu else 1:
+ *     gres[M][N] = v * mask (optional),   gx[M][K] = (v * mask * scale[n]) . w,   weight given transposed, wt[K][N].
+ * g2 (optional): the second gradient meeting at a residual join.  g3 (optional, with sub_w = OW, sub_hw = OH*OW,
+ * M = B*4*OH*OW): a gradient living on the stride-2 grid, [M/4][N]; pixel (n,h,w) receives g3[(n,h/2,w/2)] for even
+ * h and w (the zero-upsampled tensor is never materialised).  N % 64 == 0, K % 64 == 0, N <= 2048.
  * With the forward's prologue (xin = the raw x, pscale, pshift) the result is the gradient wrt xin:
  *     gx *= [xin * pscale + pshift > 0] * pscale. */
 int adil_pw_conv_bwd(const void* g, const void* g2, const void* y, const float* scale, const void* wt, void* gx, void* gres,
-                     int M, int K, int N, int relu, const void* xin, const float* pscale, const float* pshift, void* stream);
+                     int M, int K, int N, int relu, const void* xin, const float* pscale, const float* pshift, const void* g3,
+                     int sub_w, int sub_hw, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution of the frozen network on channels_last storage, raw bf16 output (its BatchNorm +
  * ReLU run in the next pointwise kernel's prologue):  y[B][H][W][N] = conv3x3(x[B][H][W][C]; wp), weights packed

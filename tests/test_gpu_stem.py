@@ -141,7 +141,7 @@ def test_pointwise_conv_fused_epilogue(m, k, n, relu, has_res):
     if k <= 512 and has_res:                       # also exercise the fused prologue x' = relu(x * pscale + pshift)
         pre = ((0.5 + torch.rand(k, generator=gen)).to(DEV), (torch.randn(k, generator=gen) * 0.3).to(DEV))
     assert lib.adil_pw_conv_fwd(o._ptr(x), o._ptr(w), o._ptr(scale), o._ptr(shift), o._ptr(res), o._ptr(y), m, k, n, int(relu),
-                                o._ptr(pre[0] if pre else None), o._ptr(pre[1] if pre else None), o._stream()) == 0
+                                o._ptr(pre[0] if pre else None), o._ptr(pre[1] if pre else None), 0, 0, o._stream()) == 0
     xe = torch.relu(x.float() * pre[0] + pre[1]).bfloat16().float() if pre else x.float()
     ref = (xe @ w.float().t()) * scale + shift
     if has_res:
@@ -175,7 +175,7 @@ def test_pointwise_conv_fused_backward(m, k, n, relu, has_res, has_g2):
         xin = torch.randn(m, k, generator=gen).bfloat16().to(DEV)
         ps, pb = (0.5 + torch.rand(k, generator=gen)).to(DEV), (torch.randn(k, generator=gen) * 0.3).to(DEV)
     assert lib.adil_pw_conv_bwd(o._ptr(g), o._ptr(g2), o._ptr(y), o._ptr(scale), o._ptr(wt), o._ptr(gx), o._ptr(gres), m, k, n,
-                                int(relu), o._ptr(xin), o._ptr(ps), o._ptr(pb), o._stream()) == 0
+                                int(relu), o._ptr(xin), o._ptr(ps), o._ptr(pb), None, 0, 0, o._stream()) == 0
     v = g.float() + (g2.float() if has_g2 else 0.0)
     if relu:
         v = v * (y > 0)
@@ -249,3 +249,40 @@ def test_conv3x3_forward_and_input_gradient(b, h, w_, c, n):
     gref = xin.grad.permute(0, 2, 3, 1).reshape(-1, c)
     gerr = (gx.float() - gref).abs()
     assert bool((gerr <= 2 ** -7 * gref.abs() + 2e-3).all()), float(gerr.max())
+
+
+@pytest.mark.parametrize("b,oh,ow,k,n", [(2, 14, 14, 256, 512), (3, 7, 5, 64, 128), (1, 28, 28, 256, 512)])
+def test_pointwise_conv_stride2_gather_and_compact_gradient(b, oh, ow, k, n):
+    """Stride-2 1x1 convolution read through the in-kernel gather (forward), and the stride-2 gradient added into a
+    full-resolution backward without materialising the zero-upsampled tensor."""
+    o = ops()
+    lib = __import__("dl_attack_on_imagenet_amd._lib", fromlist=["x"]).load()
+    gen = torch.Generator().manual_seed(b + oh + ow + k + n)
+    h, w_ = 2 * oh, 2 * ow
+    xfull = torch.randn(b, h, w_, k, generator=gen).bfloat16().to(DEV)                 # NHWC
+    w = (torch.randn(n, k, generator=gen) / k ** 0.5).bfloat16().to(DEV)
+    scale = (0.5 + torch.rand(n, generator=gen)).to(DEV); shift = (torch.randn(n, generator=gen) * 0.3).to(DEV)
+    m = b * oh * ow
+    y = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+    assert lib.adil_pw_conv_fwd(o._ptr(xfull), o._ptr(w), o._ptr(scale), o._ptr(shift), None, o._ptr(y), m, k, n, 0, None, None,
+                                ow, oh * ow, o._stream()) == 0
+    ref = (xfull[:, ::2, ::2].reshape(m, k).float() @ w.float().t()) * scale + shift
+    assert bool(((y.float() - ref).abs() <= 2 ** -7 * ref.abs() + 2e-3).all())
+    # backward of a full-resolution layer (channels n2 -> k2) receiving g, g2 and a stride-2 g3
+    n2, k2 = k, 64
+    mf = b * h * w_
+    g = torch.randn(mf, n2, generator=gen).bfloat16().to(DEV); g2 = torch.randn(mf, n2, generator=gen).bfloat16().to(DEV)
+    g3 = torch.randn(b, oh, ow, n2, generator=gen).bfloat16().to(DEV)
+    yy = torch.relu(torch.randn(mf, n2, generator=gen)).bfloat16().to(DEV)
+    wt = (torch.randn(k2, n2, generator=gen) / n2 ** 0.5).bfloat16().to(DEV)
+    sc2 = (0.5 + torch.rand(n2, generator=gen)).to(DEV)
+    gx = torch.empty(mf, k2, dtype=torch.bfloat16, device=DEV); gres = torch.empty(mf, n2, dtype=torch.bfloat16, device=DEV)
+    assert lib.adil_pw_conv_bwd(o._ptr(g), o._ptr(g2), o._ptr(yy), o._ptr(sc2), o._ptr(wt), o._ptr(gx), o._ptr(gres), mf, k2, n2, 1,
+                                None, None, None, o._ptr(g3), ow, oh * ow, o._stream()) == 0
+    up = torch.zeros(b, h, w_, n2, device=DEV)
+    up[:, ::2, ::2] = g3.float()
+    v = (g.float() + g2.float() + up.reshape(mf, n2)) * (yy > 0)
+    assert bool(((gres.float() - v).abs() <= 2 ** -7 * v.abs() + 1e-6).all())
+    gref = (v * sc2).bfloat16().float() @ wt.float().t()
+    gerr = (gx.float() - gref).abs()
+    assert bool((gerr <= 2 ** -6 * gref.abs() + 3e-2).all()) and float(gerr.mean()) < 4e-3

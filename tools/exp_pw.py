@@ -25,7 +25,7 @@ for (hw, k, n, has_res), mu in zip(shapes, mult):
     sc = torch.rand(n, device=dev) + 0.5; sh = torch.randn(n, device=dev)
     r = torch.randn(m, n, device=dev, dtype=torch.bfloat16) if has_res else None
     y = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
-    t = timeit(lambda: lib.adil_pw_conv_fwd(ops._ptr(x), ops._ptr(w), ops._ptr(sc), ops._ptr(sh), ops._ptr(r), ops._ptr(y), m, k, n, 1, None, None, ops._stream()))
+    t = timeit(lambda: lib.adil_pw_conv_fwd(ops._ptr(x), ops._ptr(w), ops._ptr(sc), ops._ptr(sh), ops._ptr(r), ops._ptr(y), m, k, n, 1, None, None, 0, 0, ops._stream()))
     byt = (m * k + m * n * (2 if has_res else 1) + n * k) * 2
     fl = byt / 5.3e6
     tot += t * mu; tot_floor += fl * mu
@@ -43,7 +43,7 @@ for (hw, k, n, has_res), mu in zip(shapes, mult):
     sc = torch.rand(n, device=dev) + 0.5
     gx = torch.empty(m, k, device=dev, dtype=torch.bfloat16)
     gres = torch.empty(m, n, device=dev, dtype=torch.bfloat16) if has_res else None
-    t = timeit(lambda: lib.adil_pw_conv_bwd(ops._ptr(g), ops._ptr(g2), ops._ptr(yy), ops._ptr(sc), ops._ptr(wt), ops._ptr(gx), ops._ptr(gres), m, k, n, 1, None, None, None, ops._stream()))
+    t = timeit(lambda: lib.adil_pw_conv_bwd(ops._ptr(g), ops._ptr(g2), ops._ptr(yy), ops._ptr(sc), ops._ptr(wt), ops._ptr(gx), ops._ptr(gres), m, k, n, 1, None, None, None, None, 0, 0, ops._stream()))
     byt = (m * k + m * n * (4 if has_res else 2) + n * k) * 2
     fl = byt / 5.3e6
     tot += t * mu; tot_floor += fl * mu
