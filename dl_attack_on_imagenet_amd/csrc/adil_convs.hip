@@ -620,7 +620,7 @@ int launch_conv3x3(const void* x, const void* wp, void* y, int M, int H, int W, 
 
 extern "C" int adil_conv3x3(const void* x, const void* wp, void* y, int B, int H, int W, int C, int N, void* stream) {
     ADIL_ENTER();
-    if (!x || !wp || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || (C % 64) || (N % 64) || W > 256) return ADIL_EINVAL;
+    if (!x || !wp || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || (C % 64) || (N % 64) || W > 63) return ADIL_EINVAL;   // halo = 128 + 2W + 2 pixels <= 256
     const long long M = (long long)B * H * W;
     if (M > 0x7fffffffLL) return ADIL_EINVAL;
     if (N % 128 == 0) return launch_conv3x3<128>(x, wp, y, (int)M, H, W, C, N, (hipStream_t)stream);

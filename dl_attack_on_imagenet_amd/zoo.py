@@ -416,7 +416,7 @@ class _ConvAffine(nn.Module):
 
     def raw_conv(self, x):
         """The convolution alone (no BatchNorm / ReLU): the hand-written 3x3 kernel where it applies, else the library."""
-        if self.dense3x3 and x.is_cuda and x.dtype == torch.bfloat16:
+        if self.dense3x3 and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] <= 63:   # kernel limit: W <= 63
             from . import ops
             return ops.conv3x3(x, self.wp_fwd, self.wp_bwd)
         return self.conv(x)

@@ -188,7 +188,7 @@ int adil_pw_conv_bwd(const void* g, const void* g2, const void* y, const float* 
 /* 3x3 / stride 1 / pad 1 convolution of the frozen network on channels_last storage, raw bf16 output (its BatchNorm +
  * ReLU run in the next pointwise kernel's prologue):  y[B][H][W][N] = conv3x3(x[B][H][W][C]; wp), weights packed
  * wp[N][9][C] = w[n][c][kh][kw] at [n][kh*3+kw][c].  The input gradient is the same call on wp' [C][9][N] =
- * w[n][c][2-kh][2-kw] at [c][kh*3+kw][n].  C % 64 == 0, N % 64 == 0. */
+ * w[n][c][2-kh][2-kw] at [c][kh*3+kw][n].  C % 64 == 0, N % 64 == 0, W <= 63. */
 int adil_conv3x3(const void* x, const void* wp, void* y, int B, int H, int W, int C, int N, void* stream);
 
 #ifdef __cplusplus
