@@ -51,7 +51,7 @@ SIGNATURES = {
                                    c_void_p]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

@@ -327,7 +327,7 @@ static inline int stream_grid(size_t work_items, int per_block) {
     return (int)b;
 }
 
-extern "C" int adil_abi_version(void) { return 1; }
+extern "C" int adil_abi_version(void) { return 2; }
 extern "C" int adil_max_atoms(void) { return ADIL_MAX_ATOMS; }
 
 extern "C" int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, void* stream) {

@@ -38,7 +38,7 @@ extern "C" {
 #define ADIL_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported K) */
 #define ADIL_EWORKSPACE (-2) /* workspace too small */
 
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header (currently 2: v2 added the frozen-classifier entry points); bumped on any signature change. */
 int adil_abi_version(void);
 
 /* Largest K (atoms) the kernels support. */
