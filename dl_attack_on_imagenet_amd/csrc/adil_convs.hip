@@ -103,16 +103,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRO && BN =
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
             u32x4 t = xr[i];
             if (pro) {
-                float v[8];
-                unpack8(t, v);
-                const float* ps = spro + kc * PW_BK + ch * 8;
-                const float4 a0 = *reinterpret_cast<const float4*>(ps), a1 = *reinterpret_cast<const float4*>(ps + 4);
-                const float4 b0 = *reinterpret_cast<const float4*>(ps + PW_PK), b1 = *reinterpret_cast<const float4*>(ps + PW_PK + 4);
-                v[0] = fmaxf(v[0] * a0.x + b0.x, 0.0f); v[1] = fmaxf(v[1] * a0.y + b0.y, 0.0f);
-                v[2] = fmaxf(v[2] * a0.z + b0.z, 0.0f); v[3] = fmaxf(v[3] * a0.w + b0.w, 0.0f);
-                v[4] = fmaxf(v[4] * a1.x + b1.x, 0.0f); v[5] = fmaxf(v[5] * a1.y + b1.y, 0.0f);
-                v[6] = fmaxf(v[6] * a1.z + b1.z, 0.0f); v[7] = fmaxf(v[7] * a1.w + b1.w, 0.0f);
-                t = pack8(v);
+                const f32x2* ps = reinterpret_cast<const f32x2*>(spro + kc * PW_BK + ch * 8);
+                const f32x2* pb = reinterpret_cast<const f32x2*>(spro + PW_PK + kc * PW_BK + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = relu_bf2(f32x2_to_bf2(bf2_to_f32x2(t[j]) * ps[j] + pb[j]));
             }
             *reinterpret_cast<u32x4*>(sx + row * PW_LS + ch * 8) = t;
         }
@@ -159,21 +153,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRO && BN =
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int co = 32 * ct + 8 * q + 4 * h;
-            const float4 sc = *reinterpret_cast<const float4*>(ssc + co);
-            const float4 sh = *reinterpret_cast<const float4*>(ssc + BN + co);
-            float v[4] = {acc[ct][4 * q] * sc.x + sh.x, acc[ct][4 * q + 1] * sc.y + sh.y,
-                          acc[ct][4 * q + 2] * sc.z + sh.z, acc[ct][4 * q + 3] * sc.w + sh.w};
+            const f32x2* sc = reinterpret_cast<const f32x2*>(ssc + co);
+            const f32x2* sh = reinterpret_cast<const f32x2*>(ssc + BN + co);
+            f32x2 v0 = f32x2{acc[ct][4 * q], acc[ct][4 * q + 1]} * sc[0] + sh[0];
+            f32x2 v1 = f32x2{acc[ct][4 * q + 2], acc[ct][4 * q + 3]} * sc[1] + sh[1];
             if (res != nullptr) {
-                v[0] += __uint_as_float(rr[ct][q][0] << 16); v[1] += __uint_as_float(rr[ct][q][0] & 0xffff0000u);
-                v[2] += __uint_as_float(rr[ct][q][1] << 16); v[3] += __uint_as_float(rr[ct][q][1] & 0xffff0000u);
-            }
-            if (relu) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                v0 += bf2_to_f32x2(rr[ct][q][0]);
+                v1 += bf2_to_f32x2(rr[ct][q][1]);
             }
             u32x2 t;
-            t[0] = pack2_bf16(v[0], v[1]);
-            t[1] = pack2_bf16(v[2], v[3]);
+            t[0] = f32x2_to_bf2(v0);
+            t[1] = f32x2_to_bf2(v1);
+            if (relu) { t[0] = relu_bf2(t[0]); t[1] = relu_bf2(t[1]); }
             *reinterpret_cast<u32x2*>(so + c * OS + co) = t;
         }
     }
@@ -261,30 +252,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BO == 128 
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-            float v[8], t8[8];
-            unpack8(gr[i], v);
-            if (g2 != nullptr) {
-                unpack8(hr[i], t8);
+            const f32x2* s2 = reinterpret_cast<const f32x2*>(ssc + nc * PW_BK + ch * 8);
+            u32x4 rs, gz;                                             // gres chunk, gz chunk (packed bf16)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += t8[j];
-            }
-            if (G3) {
-                unpack8(tr[i], t8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += t8[j] * g3on[i];
-            }
-            if (relu) {
-                unpack8(yr[i], t8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = t8[j] > 0.0f ? v[j] : 0.0f;
+            for (int j = 0; j < 4; ++j) {
+                f32x2 v = bf2_to_f32x2(gr[i][j]);
+                if (g2 != nullptr) v += bf2_to_f32x2(hr[i][j]);
+                if (G3) v += bf2_to_f32x2(tr[i][j]) * g3on[i];
+                const unsigned m = relu ? pos_mask_bf2(yr[i][j]) : 0xffffffffu;
+                rs[j] = f32x2_to_bf2(v) & m;
+                gz[j] = f32x2_to_bf2(v * s2[j]) & m;
             }
             const int mm = m0 + row;
-            if (write_res && mm < M) *reinterpret_cast<u32x4*>(gres + (size_t)mm * N + nc * PW_BK + ch * 8) = pack8(v);
-            const float4 s0 = *reinterpret_cast<const float4*>(ssc + nc * PW_BK + ch * 8);
-            const float4 s1 = *reinterpret_cast<const float4*>(ssc + nc * PW_BK + ch * 8 + 4);
-            v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w;
-            v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w;
-            *reinterpret_cast<u32x4*>(sx + row * PW_LS + ch * 8) = pack8(v);
+            if (write_res && mm < M) *reinterpret_cast<u32x4*>(gres + (size_t)mm * N + nc * PW_BK + ch * 8) = rs;
+            *reinterpret_cast<u32x4*>(sx + row * PW_LS + ch * 8) = gz;
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {

@@ -40,4 +40,28 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
     return t;
 }
 
+// ---- packed elementwise helpers: two values per VALU instruction (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 on
+// fp32 pairs, v_pk_*_i16 on packed bf16).  The GEMM kernels' pro/epilogues were VALU-bound with scalar code: 670 VALU
+// instructions per wave against 64 MFMAs on a stage-3 pointwise layer (SQ_INSTS_VALU / SQ_INSTS_MFMA).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 bf2_to_f32x2(unsigned u) {
+    return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
+__device__ __forceinline__ unsigned f32x2_to_bf2(f32x2 v) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// ReLU on a packed bf16 pair: as int16 a negative float is a negative integer -> one v_pk_max_i16
+__device__ __forceinline__ unsigned relu_bf2(unsigned p) {
+    const i16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, p), z));
+}
+// 0xffff per half where the bf16 value is > 0 (y never holds -0.0: it is a ReLU output), else 0
+__device__ __forceinline__ unsigned pos_mask_bf2(unsigned y) {
+    const i16x2 z = {0, 0};
+    const i16x2 s = z - __builtin_bit_cast(i16x2, y);
+    return __builtin_bit_cast(unsigned, s >> 15);
+}
+
 }  // namespace
