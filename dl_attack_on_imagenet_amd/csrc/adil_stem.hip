@@ -226,8 +226,8 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const bf16_t* __rest
 //   g_x[ci][ih][iw] = inv_std[ci] * sum_{kh,kw,co} g_y1[(ih+3-kh)/2][(iw+3-kw)/2][co] * w[co][ci][kh][kw]
 //   over the taps with even ih+3-kh, iw+3-kw: the input pixels split into 4 parity classes (ih&1, iw&1) with
 //   3 or 4 taps per axis.  Workgroup = 16 x 32 input pixels of one image = 4 classes x (8 x 16) pixels; wave w takes
-//   sub-rows 2w, 2w+1 of every class.  MFMA roles: A = weights (rows = ci, 3 of 32 used: the waste is irrelevant next
-//   to the 822 MB g_y1 stream), B = g_y1 patches (columns = pixels; 8 consecutive co = one aligned 16-byte LDS read).
+//   sub-rows 2w, 2w+1 of every class.  MFMA roles: A = weights (rows = ci, 3 of 16 used, mfma_16x16x32), B = g_y1 patches
+//   (columns = pixels; 8 consecutive co = one aligned 16-byte LDS read).
 // =========================================================================================================== //
 #define SB_TH 16
 #define SB_TW 32
@@ -235,20 +235,30 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const bf16_t* __rest
 #define SB_GC (SB_TW / 2 + 3)          // 19 g_y1 columns
 #define SB_PS 72                       // g_y1 pixel stride in LDS (elements): 144 B = 9 x 16 B
 
+// v_mfma_f32_16x16x32_bf16: A lane l -> row l&15, k = 8*(l>>4)+j; B lane l -> column l&15, same k; C register r of
+// lane l -> row 4*(l>>4)+r, column l&15 (layout checked on hardware).  With only 3 useful rows (ci) the 16-row shape
+// wastes half as many MFMA cycles as 32x32x16: 16 pixels x 32 channels of K per instruction, 4 passes.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <int A, int BB>
-__device__ __forceinline__ void stem_bwd_class(f32x16& acc, const bf16_t* sg, const bf16_t* swb, int sr, int sc, int c, int h) {
-    const int wrow = (c < 3 ? c : 3) * 49 * 64;
-#pragma unroll
+__device__ __forceinline__ void stem_bwd_class(f32x4 (&acc)[2], const bf16_t* sg, const bf16_t* swb, int w, int l16, int ks) {
+    const int wrow = (l16 < 3 ? l16 : 0) * 49 * 64;
+    const bool wlane = l16 < 3;                            // only 3 of the 16 A rows exist: the other lanes skip the LDS read
+#pragma unroll 1                                           // rolled: a fully unrolled 196-MFMA body hoists LDS reads into spills
     for (int kh = 1 - A; kh < 7; kh += 2) {
-        const int row = sr + (A + 3 - kh) / 2 + 1;
 #pragma unroll
         for (int kw = 1 - BB; kw < 7; kw += 2) {
-            const int col = sc + (BB + 3 - kw) / 2 + 1;
+            const int col = l16 + (BB + 3 - kw) / 2 + 1;
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg) {
-                const bf16x8 a = lds8(swb + wrow + (kh * 7 + kw) * 64 + 16 * cg + 8 * h);
-                const bf16x8 b = lds8(sg + (row * SB_GC + col) * SB_PS + 16 * cg + 8 * h);
-                mma16(acc, a, b);
+            for (int cg = 0; cg < 2; ++cg) {
+                bf16x8 a = {};
+                if (wlane) a = lds8(swb + wrow + (kh * 7 + kw) * 64 + 32 * cg + 8 * ks);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int row = 2 * w + q + (A + 3 - kh) / 2 + 1;
+                    const bf16x8 b = lds8(sg + (row * SB_GC + col) * SB_PS + 32 * cg + 8 * ks);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[q], 0, 0, 0);
+                }
             }
         }
     }
@@ -263,14 +273,14 @@ template <> __device__ __forceinline__ void st_pair<bf16_t>(bf16_t* p, float a, 
 }
 
 template <typename TX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void stem_conv_bwd_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ wb,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void stem_conv_bwd_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ wb,
                                                             StemNorm nm, TX* __restrict__ gx, int H, int W, int OH,
                                                             int OW) {
     __shared__ __attribute__((aligned(16))) bf16_t sg[SB_GR * SB_GC * SB_PS];
-    __shared__ __attribute__((aligned(16))) bf16_t swb[4 * 49 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t swb[3 * 49 * 64];   // the zero row (ci = 3) of w_bwd is never read
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int n = blockIdx.z, ih0 = blockIdx.y * SB_TH, iw0 = blockIdx.x * SB_TW;
-    for (int q = tid; q < 4 * 49 * 8; q += 256)
+    for (int q = tid; q < 3 * 49 * 8; q += 256)
         *reinterpret_cast<u32x4*>(swb + q * 8) = *reinterpret_cast<const u32x4*>(wb + q * 8);
     const int ohb = ih0 / 2 - 1, owb = iw0 / 2 - 1;
     for (int q = tid; q < SB_GR * SB_GC * 8; q += 256) {
@@ -283,26 +293,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         *reinterpret_cast<u32x4*>(sg + px * SB_PS + ch * 8) = t;
     }
     lds_sync();
-    const int sr = 2 * w + (c >> 4), sc = c & 15;          // this lane's pixel of the class sub-grid
-    f32x16 acc[4];
+    const int l16 = lane & 15, ks = lane >> 4;             // pixel column of the class sub-grid / K slice of this lane
+    f32x4 acc[4][2];                                       // [parity class][sub-row 2w + q]
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
-    stem_bwd_class<0, 0>(acc[0], sg, swb, sr, sc, c, h);
-    stem_bwd_class<0, 1>(acc[1], sg, swb, sr, sc, c, h);
-    stem_bwd_class<1, 0>(acc[2], sg, swb, sr, sc, c, h);
-    stem_bwd_class<1, 1>(acc[3], sg, swb, sr, sc, c, h);
-    if (h == 0) {                                          // accumulator rows 0..2 (= ci) live in registers 0..2 of h = 0
-        const int iw = iw0 + 2 * sc;
+        for (int q = 0; q < 2; ++q) acc[k][q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    stem_bwd_class<0, 0>(acc[0], sg, swb, w, l16, ks);
+    stem_bwd_class<0, 1>(acc[1], sg, swb, w, l16, ks);
+    stem_bwd_class<1, 0>(acc[2], sg, swb, w, l16, ks);
+    stem_bwd_class<1, 1>(acc[3], sg, swb, w, l16, ks);
+    if (ks == 0) {                                         // accumulator rows 0..2 (= ci) are registers 0..2 of lanes 0..15
+        const int iw = iw0 + 2 * l16;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int ih = ih0 + 2 * sr + a;
-            if (ih < H && iw < W) {
+        for (int q = 0; q < 2; ++q) {
 #pragma unroll
-                for (int ci = 0; ci < 3; ++ci) {
-                    TX* o = gx + (((size_t)n * 3 + ci) * H + ih) * W + iw;
-                    st_pair<TX>(o, acc[2 * a][ci] * nm.inv_std[ci], acc[2 * a + 1][ci] * nm.inv_std[ci]);
+            for (int a = 0; a < 2; ++a) {
+                const int ih = ih0 + 2 * (2 * w + q) + a;
+                if (ih < H && iw < W) {
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) {
+                        TX* o = gx + (((size_t)n * 3 + ci) * H + ih) * W + iw;
+                        st_pair<TX>(o, acc[2 * a][q][ci] * nm.inv_std[ci], acc[2 * a + 1][q][ci] * nm.inv_std[ci]);
+                    }
                 }
             }
         }
