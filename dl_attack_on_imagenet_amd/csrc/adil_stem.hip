@@ -43,13 +43,17 @@ template <> __device__ __forceinline__ float ld_px<bf16_t>(const bf16_t* p, size
 #define ST_OS 72                       // staged-output pixel stride (elements)
 
 template <typename TX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void stem_conv_fwd_kernel(const TX* __restrict__ x, const bf16_t* __restrict__ wf,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void stem_conv_fwd_kernel(const TX* __restrict__ x, const bf16_t* __restrict__ wf,
                                                             StemNorm nm, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, bf16_t* __restrict__ y,
                                                             int H, int W, int OH, int OW) {
-    __shared__ __attribute__((aligned(16))) bf16_t sin[ST_ROWS * ST_RS];
-    __shared__ __attribute__((aligned(16))) bf16_t sw[64 * ST_WS];
-    __shared__ __attribute__((aligned(16))) bf16_t sout[4 * 32 * ST_OS];
+    // one LDS block: [input tile | weights]; the per-wave output-transpose scratch aliases it once the MFMAs are done
+    // (42 KB instead of 60 KB: 3 workgroups per CU)
+    __shared__ __attribute__((aligned(16))) bf16_t smem[ST_ROWS * ST_RS + 64 * ST_WS];
+    static_assert(4 * 32 * ST_OS <= ST_ROWS * ST_RS + 64 * ST_WS, "output scratch must fit in the tile buffers");
+    bf16_t* sin = smem;
+    bf16_t* sw = smem + ST_ROWS * ST_RS;
+    bf16_t* sout = smem;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int n = blockIdx.z, oh0 = blockIdx.y * ST_T, ow0 = blockIdx.x * ST_T;
     // weights: 64 rows x 224 bf16 = 28 chunks of 16 B per row
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][ct][r] = 0.0f;
     const int prow = c >> 4, pcol = c & 15;
-#pragma unroll
+#pragma unroll 1
     for (int kh = 0; kh < 7; ++kh) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -102,6 +106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         }
     }
     // epilogue: BN affine + ReLU, per-wave transpose through LDS, 16-byte NHWC stores
+    lds_sync();                                            // every wave is done reading the tiles the scratch aliases
     bf16_t* so = sout + w * 32 * ST_OS;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
