@@ -57,25 +57,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int n = blockIdx.z, oh0 = blockIdx.y * ST_T, ow0 = blockIdx.x * ST_T;
     // weights: 64 rows x 224 bf16 = 28 chunks of 16 B per row
-    for (int q = tid; q < 64 * 28; q += 256) {
-        const int co = q / 28, off = q - co * 28;
-        *reinterpret_cast<u32x4*>(sw + co * ST_WS + off * 8) = *reinterpret_cast<const u32x4*>(wf + co * ST_K + off * 8);
+    {
+        u32x4 wv[7];                                       // 64 * 28 = 7 * 256 chunks: all in flight together
+#pragma unroll
+        for (int j = 0; j < 7; ++j) wv[j] = *reinterpret_cast<const u32x4*>(wf + (size_t)(tid + 256 * j) * 8);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int q = tid + 256 * j, co = q / 28, off = q - co * 28;
+            *reinterpret_cast<u32x4*>(sw + co * ST_WS + off * 8) = wv[j];
+        }
     }
     // input tile, normalised, zero outside the image (the padding of the normalised tensor), 4th channel zero
     const TX* xn = x + (size_t)n * 3 * H * W;
-    for (int pos = tid; pos < ST_ROWS * ST_COLS; pos += 256) {
+    // (all 18 loads of a thread are issued before the first conversion: a rolled loop pays one memory round trip per
+    // position)
+    constexpr int NPOS = (ST_ROWS * ST_COLS + 255) / 256;
+    float raw[NPOS][3], okm[NPOS];
+#pragma unroll
+    for (int j = 0; j < NPOS; ++j) {
+        const int pos = tid + 256 * j < ST_ROWS * ST_COLS ? tid + 256 * j : ST_ROWS * ST_COLS - 1;
         const int row = pos / ST_COLS, col = pos - row * ST_COLS;
         const int ih = 2 * oh0 - 3 + row, iw = 2 * ow0 - 3 + col;
         const bool ok = (ih >= 0) && (ih < H) && (iw >= 0) && (iw < W);
         const size_t at = (size_t)(ok ? ih : 0) * W + (ok ? iw : 0);
-        const float m = ok ? 1.0f : 0.0f;
-        const float v0 = (ld_px<TX>(xn, at) - nm.mean[0]) * nm.inv_std[0] * m;
-        const float v1 = (ld_px<TX>(xn + (size_t)H * W, at) - nm.mean[1]) * nm.inv_std[1] * m;
-        const float v2 = (ld_px<TX>(xn + (size_t)2 * H * W, at) - nm.mean[2]) * nm.inv_std[2] * m;
+        okm[j] = ok ? 1.0f : 0.0f;
+        raw[j][0] = ld_px<TX>(xn, at);
+        raw[j][1] = ld_px<TX>(xn + (size_t)H * W, at);
+        raw[j][2] = ld_px<TX>(xn + (size_t)2 * H * W, at);
+    }
+#pragma unroll
+    for (int j = 0; j < NPOS; ++j) {
+        const int pos = tid + 256 * j;
+        const int row = pos / ST_COLS, col = pos - row * ST_COLS;
+        const float v0 = (raw[j][0] - nm.mean[0]) * nm.inv_std[0] * okm[j];
+        const float v1 = (raw[j][1] - nm.mean[1]) * nm.inv_std[1] * okm[j];
+        const float v2 = (raw[j][2] - nm.mean[2]) * nm.inv_std[2] * okm[j];
         u32x2 t;
         t[0] = pack2_bf16(v0, v1);
         t[1] = pack2_bf16(v2, 0.0f);
-        *reinterpret_cast<u32x2*>(sin + row * ST_RS + col * 4) = t;
+        if (pos < ST_ROWS * ST_COLS) *reinterpret_cast<u32x2*>(sin + row * ST_RS + col * 4) = t;
     }
     lds_sync();
     // wave w: pixel tiles 2w, 2w+1 (tile t = conv rows 2t, 2t+1 x 16 columns; lane c <-> (c / 16, c % 16))
@@ -285,17 +305,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
     __shared__ __attribute__((aligned(16))) bf16_t swb[3 * 49 * 64];   // the zero row (ci = 3) of w_bwd is never read
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int n = blockIdx.z, ih0 = blockIdx.y * SB_TH, iw0 = blockIdx.x * SB_TW;
-    for (int q = tid; q < 3 * 49 * 8; q += 256)
-        *reinterpret_cast<u32x4*>(swb + q * 8) = *reinterpret_cast<const u32x4*>(wb + q * 8);
-    const int ohb = ih0 / 2 - 1, owb = iw0 / 2 - 1;
-    for (int q = tid; q < SB_GR * SB_GC * 8; q += 256) {
-        const int ch = q & 7, px = q >> 3;
-        const int row = px / SB_GC, col = px - row * SB_GC;
-        const int oh = ohb + row, ow = owb + col;
-        const bool ok = (oh >= 0) && (oh < OH) && (ow >= 0) && (ow < OW);
-        u32x4 t = *reinterpret_cast<const u32x4*>(gy + (((size_t)n * OH + (ok ? oh : 0)) * OW + (ok ? ow : 0)) * 64 + ch * 8);
-        if (!ok) t = u32x4{0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(sg + px * SB_PS + ch * 8) = t;
+    {   // weights (3 * 49 * 8 = 1176 chunks) and the g_y1 tile (11 * 19 * 8 = 1672 chunks): every load of a thread is in
+        // flight before the first LDS store (rolled loops paid one memory round trip per chunk: 11 per workgroup)
+        constexpr int NWQ = (3 * 49 * 8 + 255) / 256, NGQ = (SB_GR * SB_GC * 8 + 255) / 256;
+        u32x4 wv[NWQ], gv[NGQ];
+        bool gok[NGQ];
+#pragma unroll
+        for (int j = 0; j < NWQ; ++j) {
+            const int q = tid + 256 * j < 3 * 49 * 8 ? tid + 256 * j : 3 * 49 * 8 - 1;
+            wv[j] = *reinterpret_cast<const u32x4*>(wb + q * 8);
+        }
+        const int ohb = ih0 / 2 - 1, owb = iw0 / 2 - 1;
+#pragma unroll
+        for (int j = 0; j < NGQ; ++j) {
+            const int q = tid + 256 * j < SB_GR * SB_GC * 8 ? tid + 256 * j : SB_GR * SB_GC * 8 - 1;
+            const int ch = q & 7, px = q >> 3;
+            const int row = px / SB_GC, col = px - row * SB_GC;
+            const int oh = ohb + row, ow = owb + col;
+            gok[j] = (oh >= 0) && (oh < OH) && (ow >= 0) && (ow < OW);
+            gv[j] = *reinterpret_cast<const u32x4*>(gy + (((size_t)n * OH + (gok[j] ? oh : 0)) * OW + (gok[j] ? ow : 0)) * 64 + ch * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < NWQ; ++j) {
+            const int q = tid + 256 * j;
+            if (q < 3 * 49 * 8) *reinterpret_cast<u32x4*>(swb + q * 8) = wv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NGQ; ++j) {
+            const int q = tid + 256 * j;
+            const int ch = q & 7, px = q >> 3;
+            u32x4 t = gv[j];
+            if (!gok[j]) t = u32x4{0u, 0u, 0u, 0u};
+            if (q < SB_GR * SB_GC * 8) *reinterpret_cast<u32x4*>(sg + px * SB_PS + ch * 8) = t;
+        }
     }
     lds_sync();
     const int l16 = lane & 15, ks = lane >> 4;             // pixel column of the class sub-grid / K slice of this lane
