@@ -65,7 +65,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRO && BN =
     __shared__ __attribute__((aligned(16))) float spro[PRO ? 2 * PW_PK : 4];
     constexpr bool pro = PRO;
     if (pro) {
-        for (int i = tid; i < K; i += 256) { spro[i] = pscale[i]; spro[PW_PK + i] = pshift[i]; }
+        const int i2 = 2 * tid < K ? 2 * tid : 0;                            // K <= 512: one float2 of each per thread
+        const float2 a = *reinterpret_cast<const float2*>(pscale + i2), b = *reinterpret_cast<const float2*>(pshift + i2);
+        if (2 * tid < K) {
+            *reinterpret_cast<float2*>(spro + 2 * tid) = a;
+            *reinterpret_cast<float2*>(spro + PW_PK + 2 * tid) = b;
+        }
         __syncthreads();
     }
 
@@ -211,7 +216,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BO == 128 
     const int nn = N / PW_BK;
     const bool write_res = (gres != nullptr) && (ot == 0);
     __shared__ __attribute__((aligned(16))) float ssc[2048];     // BatchNorm scale of every reduction channel
-    for (int i = tid; i < N; i += 256) ssc[i] = scale[i];
+    {   // N <= 2048 floats = at most two float4 per thread, both in flight together (a rolled scalar loop pays up to
+        // eight memory round trips before the first tile load is even issued)
+        float4 sv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i4 = tid + 256 * j;
+            sv[j] = *reinterpret_cast<const float4*>(scale + (4 * i4 < N ? 4 * i4 : 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i4 = tid + 256 * j;
+            if (4 * i4 < N) *reinterpret_cast<float4*>(ssc + 4 * i4) = sv[j];
+        }
+    }
     __syncthreads();
 
     // G3: a third incoming gradient that lives on the stride-2 grid (it comes back from a stride-2 downsample
