@@ -434,14 +434,15 @@ extern "C" int adil_pw_conv_fwd(const void* x, const void* w, const float* scale
 // =========================================================================================================== //
 namespace {
 
-#define C3_BM 128
 #define C3_LS 72
 
-template <int BN>
+template <int BN, int WPX>                              // WPX waves along pixels (64 each) x 4/WPX along channels
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv3x3_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_t* __restrict__ y, int M, int H, int W, int C, int N,
     int MT, int NT) {
-    constexpr int CTW = BN / 64;                         // channel tiles per wave (waves: 2 along pixels x 2 along channels)
+    constexpr int C3_BM = WPX * 64;                      // pixels per workgroup: 128 (2 x 2 waves) or 256 (4 x 1 waves)
+    constexpr int CTW = BN / 32 / (4 / WPX);             // channel tiles per wave
+    constexpr int XCHK = (C3_BM + 128) * 8 / 256;        // halo chunks per thread (NP <= C3_BM + 128: W <= 63)
     constexpr int WCH = BN * 8 / 256;                    // 16-byte chunks of a weight tile per thread
     constexpr int OS = BN + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     const int sx_elems = (NP * C3_LS > C3_BM * OS ? NP * C3_LS : C3_BM * OS);
     bf16_t* sw = sx + ((sx_elems + 7) & ~7);             // [2][BN][C3_LS]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
-    const int wpx = w & 1, wch = w >> 1;
+    const int wpx = w % WPX, wch = w / WPX;
     int mt, nt;
     if ((MT & 7) == 0) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -481,10 +482,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         vmask[p] = vm;
     }
 
-    u32x4 xr[8], wr[3][WCH];                           // weight tiles are requested THREE taps ahead (an L2 round trip
+    u32x4 xr[XCHK], wr[3][WCH];                           // weight tiles are requested THREE taps ahead (an L2 round trip
     auto load_x = [&](int cc) {                          // is ~5x the 16 MFMAs of one tap)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < XCHK; ++i) {
             const int q = tid + 256 * i, px = q >> 3, ch = q & 7;
             int gm = m0 - W - 1 + (px < NP ? px : NP - 1);
             gm = gm < 0 ? 0 : (gm >= M ? M - 1 : gm);
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     };
     auto store_x = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < XCHK; ++i) {
             const int q = tid + 256 * i, px = q >> 3, ch = q & 7;
             if (px < NP) *reinterpret_cast<u32x4*>(sx + px * C3_LS + ch * 8) = xr[i];
         }
@@ -595,8 +596,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     }
 }
 
-template <int BN>
+template <int BN, int WPX>
 int launch_conv3x3(const void* x, const void* wp, void* y, int M, int H, int W, int C, int N, hipStream_t st) {
+    constexpr int C3_BM = WPX * 64;
     const int MT = (M + C3_BM - 1) / C3_BM, NT = N / BN;
     const int NP = C3_BM + 2 * W + 2;
     size_t sx_elems = (size_t)NP * C3_LS;
@@ -605,11 +607,11 @@ int launch_conv3x3(const void* x, const void* wp, void* y, int M, int H, int W, 
     const size_t lds = (sx_elems + (size_t)2 * BN * C3_LS) * sizeof(bf16_t);
     if (lds > 160 * 1024) return ADIL_EINVAL;
     if (lds > 48 * 1024) {
-        const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<BN, WPX>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(conv3x3_kernel<BN>, dim3((unsigned)(MT * NT)), dim3(256), lds, st, (const bf16_t*)x,
+    hipLaunchKernelGGL((conv3x3_kernel<BN, WPX>), dim3((unsigned)(MT * NT)), dim3(256), lds, st, (const bf16_t*)x,
                        (const bf16_t*)wp, (bf16_t*)y, M, H, W, C, N, MT, NT);
     ADIL_CHECK_LAUNCH();
     return 0;
@@ -622,6 +624,6 @@ extern "C" int adil_conv3x3(const void* x, const void* wp, void* y, int B, int H
     if (!x || !wp || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || (C % 64) || (N % 64) || W > 63) return ADIL_EINVAL;   // halo = 128 + 2W + 2 pixels <= 256
     const long long M = (long long)B * H * W;
     if (M > 0x7fffffffLL) return ADIL_EINVAL;
-    if (N % 128 == 0) return launch_conv3x3<128>(x, wp, y, (int)M, H, W, C, N, (hipStream_t)stream);
-    return launch_conv3x3<64>(x, wp, y, (int)M, H, W, C, N, (hipStream_t)stream);
+    if (N % 128 == 0) return launch_conv3x3<128, 2>(x, wp, y, (int)M, H, W, C, N, (hipStream_t)stream);
+    return launch_conv3x3<64, 4>(x, wp, y, (int)M, H, W, C, N, (hipStream_t)stream);   // 64 px x 64 ch wave tiles as well
 }
