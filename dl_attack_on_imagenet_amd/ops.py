@@ -259,10 +259,13 @@ def atom_norms(d: Tensor) -> Tensor:
     return norms
 
 
-def atom_l2_project_(d: Tensor, sphere: bool = False) -> Tensor:
-    """constraint_dict 'l2ball' / 'l2sphere' in place (utils.py:44-54)."""
+def atom_l2_project_(d: Tensor, sphere: bool = False, radius: float = 1.0) -> Tensor:
+    """constraint_dict 'l2ball' / 'l2sphere' in place (utils.py:44-54); radius != 1 projects every atom onto the
+    l2 ball / sphere of that radius (UAPPGD.project with its single atom, uappgd.py:60-66)."""
     lib = _lib.load()
     norms = atom_norms(d)
+    if radius != 1.0:
+        norms.div_(float(radius))                                     # d / max(|d|/r, 1) = r d / max(|d|, r)
     p, k = dict_shape(d)
     _lib.check(lib.adil_atom_scale(_ptr(d), p, k, _ptr(norms), int(bool(sphere)), _stream()), "adil_atom_scale")
     return d

@@ -763,3 +763,45 @@ def sadil_updated(model, images: Tensor, labels: Tensor, d0: Tensor, targeted: b
         if abs(loss[-1] - loss[-2]) < 1e-6:
             break
     return d, v, loss
+
+
+# --------------------------------------------------------------------------- #
+# UAPPGD baseline (uappgd.py:29-107, :166-178): ONE universal perturbation = a dictionary with a single atom and the
+# constant code 1 for every image (the reference itself writes it as tensordot(ones(B,1), attack), uappgd.py:92,96)
+# --------------------------------------------------------------------------- #
+def uappgd_project(attack: Tensor, norm: str, eps: float) -> Tensor:
+    """UAPPGD.project (uappgd.py:60-68): l2 -> rescale onto the ball, linf -> clamp."""
+    if norm.lower() == "l2":
+        nrm = torch.norm(attack, p="fro")
+        return eps * attack / nrm if nrm > eps else attack
+    return torch.clamp(attack, min=-eps, max=eps)
+
+
+def uappgd_learn(model, images: Tensor, labels: Tensor, epochs_batches, step_size: float, norm: str, eps: float,
+                 beta: float, optimizer: str, val_images: Tensor):
+    """UAPPGD.learn_attack (uappgd.py:70-107) with the loader's batch order given explicitly.
+    Returns (attack (1,C,H,W), fooling_rate: list of 0-d tensors, train fooled counts per epoch)."""
+    attack = torch.zeros((1,) + tuple(images.shape[1:]), device=images.device).requires_grad_(True)   # uappgd.py:78
+    opt = (torch.optim.SGD([attack], lr=step_size) if optimizer.lower() == "sgd"
+           else torch.optim.Adam([attack], lr=step_size))                                              # uappgd.py:81-84
+    fooling_rate, fooled_train = [], []
+    for batches in epochs_batches:
+        fool_s = 0
+        for idx in batches:
+            idx = torch.as_tensor([int(i) for i in idx], dtype=torch.int64, device=images.device)
+            x, y = images[idx], labels[idx]
+            opt.zero_grad()
+            v = torch.ones((idx.numel(), 1), device=images.device)
+            x_attack = torch.tensordot(v, attack, dims=([1], [0])) + x                                 # uappgd.py:96
+            out = model(x_attack)
+            fool_s += int((out.argmax(-1) != y).sum())
+            loss = torch.clamp_min(-F.cross_entropy(out, y, reduction="mean"), -beta)                   # uappgd.py:99-100
+            loss.backward()
+            opt.step()
+            with torch.no_grad():
+                attack.data = uappgd_project(attack.data, norm, eps)                                   # uappgd.py:104-105
+        with torch.no_grad():                                                                          # utils.py:189-200
+            pred = model(val_images).argmax(dim=1)
+            fooling_rate.append((pred != model(val_images + attack).argmax(dim=1)).sum() / val_images.shape[0])
+        fooled_train.append(fool_s)
+    return attack.detach(), fooling_rate, fooled_train

@@ -478,10 +478,57 @@ def g13_sadil_updated():
     save("g13_sadil_updated", images=images, labels=labels, l2=0.05, **state_to_npz_dict(net), **out)
 
 
+def g14_uappgd():
+    """UAPPGD baseline (uappgd.py:70-107): the universal perturbation and per-epoch validation fooling rates, for both
+    norms / optimisers; the DataLoader's shuffled order is recorded through the dataset and handed to the oracle."""
+    import importlib
+    UAP = importlib.import_module("attacks.attacks_classes.uappgd")
+    assert os.path.realpath(UAP.__file__).startswith(os.path.realpath(ref_import.REFERENCE_ROOT))
+
+    class XY(torch.utils.data.Dataset):
+        def __init__(self, images, labels):
+            self.images, self.labels, self.log = images, labels, []
+
+        def __len__(self):
+            return len(self.images)
+
+        def __getitem__(self, item):
+            if item >= len(self.images):
+                raise IndexError
+            self.log.append(int(item))
+            return self.images[item], self.labels[item]
+
+    out = {}
+    images, val, net = _learn_setup(114)
+    with torch.no_grad():
+        labels = net(images).argmax(-1)
+    n, bs, steps = images.shape[0], 8, 3
+    for tag, norm, eps, optim, lr, seed in (("linf_adam", "linf", 0.1, "adam", 0.01, 5), ("l2_sgd", "l2", 2.0, "sgd", 0.5, 6)):
+        train_ds, val_ds = XY(images, labels), XY(val, torch.zeros(len(val), dtype=torch.long))
+        with scratch_cwd():
+            os.makedirs("dict_model_ImageNet_version_constrained")
+            torch.manual_seed(seed)
+            atk = quiet(UAP.UAPPGD, net, data_train=train_ds, data_val=val_ds, steps=steps, batch_size=bs, beta=9,
+                        step_size=lr, norm=norm, eps=eps, optimizer=optim)
+            attack, fr = torch.load(atk.model_name)
+        log = train_ds.log[1:]                                   # the first access is the shape probe `dataset[0]` (uappgd.py:77)
+        assert len(log) == steps * n
+        epochs_batches = [chunk(e, bs) for e in chunk(log, n)]
+        o_attack, o_fr, o_fooled = O.uappgd_learn(net, images, labels, epochs_batches, lr, norm, eps, 9.0, optim, val)
+        e1 = close(o_attack, attack.detach(), 1e-6, "uappgd attack")
+        close(torch.stack(o_fr), torch.stack([torch.as_tensor(f) for f in fr]), 0, "uappgd fooling")
+        print(f"  g14[{tag}] oracle-vs-reference: attack {e1:.2e} |attack|max {float(attack.abs().max()):.3f} val fooling {[float(f) for f in fr]}")
+        out.update({f"{tag}_batches": np.array(epochs_batches), f"{tag}_attack": attack.detach(),
+                    f"{tag}_fooling": np.array([float(f) for f in fr]), f"{tag}_eps": eps, f"{tag}_lr": lr,
+                    f"{tag}_train_fooled": np.array(o_fooled)})
+    save("g14_uappgd", images=images, val=val, labels=labels, batch_size=bs, steps=steps, beta=9.0, **state_to_npz_dict(net), **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (g1_l1ball, g2_constraints, g3_softshrink, g4_synth_grad, g5_floss, g6_adamw_steps, g7_learn_a,
-               g8_learn_b, g9_ddrague, g10_adamw_inference, g11_unsupervised, g12_ista_and_metrics, g13_sadil_updated):
+               g8_learn_b, g9_ddrague, g10_adamw_inference, g11_unsupervised, g12_ista_and_metrics, g13_sadil_updated,
+               g14_uappgd):
         if only and fn.__name__.split("_")[0] not in only:
             continue
         print(fn.__name__)

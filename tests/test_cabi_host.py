@@ -173,9 +173,13 @@ def test_adil_constructor_surface_without_data(tmp_path):
     assert atk.device == torch.device("cpu") and "ADIL" in str(atk)
     with pytest.raises(FileNotFoundError):
         atk(torch.zeros(1, 3, 2, 2), torch.zeros(1, dtype=torch.long))
-    for cls in (ADILR, FastUAP, UAPPGD):
+    for cls in (ADILR, FastUAP):
         with pytest.raises(NotImplementedError):
             cls(net)
+    uap = UAPPGD(net, steps=2, batch_size=4, norm='linf', eps=0.1, model_dir=str(tmp_path))   # no data: nothing is learned
+    assert uap.model_name.endswith("UAPPGD_model_test.bin") and uap.optimizer == 'adam' and uap.beta == 9
+    with pytest.raises(RuntimeError):                     # learning runs on the HIP kernels only: no CPU fallback
+        uap.learn_attack(dataset=[(torch.zeros(3, 2, 2), 0)] * 4)
     lg = torch.tensor([[1.0, 3.0, -2.0], [-1.0, -3.0, -2.0]])
     out = atk.f_loss(lg, torch.tensor([1, 0]))
     assert out.tolist() == [2.0, -1.0]               # second row: other logits negative -> max is the zeroed label (Q5)

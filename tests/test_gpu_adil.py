@@ -276,3 +276,24 @@ def test_config1_resnet18_parity():
     assert fooled_cpu[-1] == fooled_gpu[-1]
     assert max(abs(a - b) for a, b in zip(loss_cpu, loss_gpu)) <= 2e-2 * max(abs(a) for a in loss_cpu)
     assert float((learner.v.cpu() - ov).abs().max()) <= 5e-3      # codes stay close (l1 radius 0.031)
+
+
+@pytest.mark.parametrize("tag,norm,optim", [("linf_adam", "linf", "adam"), ("l2_sgd", "l2", "sgd")])
+def test_uappgd_baseline_matches_reference_run(tag, norm, optim, tmp_path):
+    """UAPPGD (K = 1 on the ADiL kernels) replaying the reference's own run (golden G14: shuffled batch order, both norms
+    and optimisers): learned perturbation, per-epoch validation fooling rates and training fooled counts."""
+    from attacks import UAPPGD
+    from attacks.utils import QuickAttackDataset
+    z = load_golden("g14_uappgd")
+    net = tinynet_from_npz(z).to(DEV)
+    images, labels, val = t(z["images"]), t(z["labels"]).long(), t(z["val"])
+    batches = [[list(map(int, b)) for b in e] for e in z[f"{tag}_batches"]]
+    atk = UAPPGD(net, steps=int(z["steps"]), batch_size=int(z["batch_size"]), beta=float(z["beta"]),
+                 step_size=float(z[f"{tag}_lr"]), norm=norm, eps=float(z[f"{tag}_eps"]), optimizer=optim, model_dir=str(tmp_path))
+    attack = atk.learn_attack(QuickAttackDataset(images, labels), QuickAttackDataset(val, torch.zeros(len(val), dtype=torch.long)),
+                              batches=batches)
+    close(attack, z[f"{tag}_attack"], 2e-5)
+    assert [float(f) for f in atk.fooling_rate] == [float(f) for f in z[f"{tag}_fooling"]]
+    assert atk.train_fooled == [int(f) for f in z[f"{tag}_train_fooled"]]
+    adv = atk(images.to(DEV), labels.to(DEV))                         # forward: clamp(images + attack, 0, 1) from the saved file
+    close(adv, (images + t(z[f"{tag}_attack"])).clamp(0, 1), 2e-5)

@@ -175,3 +175,16 @@ def test_g13_sadil_updated(tag):
     d, v, loss = O.sadil_updated(net, t(z["images"]), t(z["labels"]), t(z[f"{tag}_d0"]), True, 3, 2, float(z[f"{tag}_lam"]),
                                  float(z["l2"]), float(z[f"{tag}_step"]))
     close(d, z[f"{tag}_d"], 5e-5); close(v, z[f"{tag}_v"], 5e-5); close(loss, z[f"{tag}_loss"], 1e-3)
+
+
+@pytest.mark.parametrize("tag,norm,optim", [("linf_adam", "linf", "adam"), ("l2_sgd", "l2", "sgd")])
+def test_g14_uappgd(tag, norm, optim):
+    """The UAPPGD baseline restatement against the reference's own run (uappgd.py:70-107), shuffled batch order as recorded."""
+    z = load_golden("g14_uappgd")
+    net = tinynet_from_npz(z)
+    batches = [[list(map(int, b)) for b in e] for e in z[f"{tag}_batches"]]
+    attack, fooling, fooled = O.uappgd_learn(net, t(z["images"]), t(z["labels"]).long(), batches, float(z[f"{tag}_lr"]), norm,
+                                             float(z[f"{tag}_eps"]), float(z["beta"]), optim, t(z["val"]))
+    close(attack, z[f"{tag}_attack"], 1e-6)
+    close(torch.stack(fooling), z[f"{tag}_fooling"], 0)
+    assert [int(f) for f in fooled] == [int(f) for f in z[f"{tag}_train_fooled"]]
