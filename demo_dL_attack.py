@@ -40,6 +40,9 @@ def build_parser():
     p.add_argument('--loss', default='logits', choices=['logits', 'ce'])
     p.add_argument('--method', default='gd', choices=['gd', 'alter'])
     p.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'])
+    p.add_argument('--fast-classifier', type=int, default=1,
+                   help='bf16 ResNets: run the frozen classifier on the hand-written stem / pointwise / 3x3 kernels '
+                        '(zoo.FusedResNet, same function up to bf16 rounding); 0 = plain PyTorch modules')
     return p
 
 
@@ -56,7 +59,9 @@ def main(args):
 
     model_name = zoo.canonical_name(args.model)
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    model = zoo.build_classifier(model_name, seed=args.seed, weights=args.weights, device=device, dtype=dtype)
+    fast = bool(args.fast_classifier) and dtype == torch.bfloat16 and zoo.canonical_name(model_name).startswith('resnet')
+    model = zoo.build_classifier(model_name, seed=args.seed, weights=args.weights, device=device, dtype=dtype,
+                                 channels_last=fast, fuse_bn_act=fast, fuse_stem=fast)
 
     if args.synthetic:
         dataset = SyntheticImageNet(num_classes=args.synthetic_classes, size=args.image_size, seed=args.seed)

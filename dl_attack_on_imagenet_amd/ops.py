@@ -336,8 +336,10 @@ class AffineActFunction(torch.autograd.Function):
         if res is not None and (res.shape != x.shape or _channel_inner(res) != inner or res.dtype != x.dtype):
             res = res.to(x.dtype).contiguous(memory_format=torch.channels_last if inner == 1 else torch.contiguous_format)
         y = torch.empty_like(x)
-        _lib.check(lib.adil_affine_act_fwd(_ptr(x), _ptr(res), _ptr(scale), _ptr(shift), _ptr(y), x.numel(), x.shape[1],
-                                           inner, int(relu), stream_dtype_code(x.dtype), _stream()), "adil_affine_act_fwd")
+        if x.numel() > 0:                                             # empty batches pass through like plain torch modules
+            _lib.check(lib.adil_affine_act_fwd(_ptr(x), _ptr(res), _ptr(scale), _ptr(shift), _ptr(y), x.numel(), x.shape[1],
+                                               inner, int(relu), stream_dtype_code(x.dtype), _stream()),
+                       "adil_affine_act_fwd")
         ctx.save_for_backward(y if relu else None, scale)
         ctx.meta = (inner, bool(relu), res is not None)
         return y
@@ -352,6 +354,8 @@ class AffineActFunction(torch.autograd.Function):
             g = g.contiguous(memory_format=torch.channels_last if inner == 1 else torch.contiguous_format)
         gx = torch.empty_like(g)
         gres = torch.empty_like(g) if has_res else None
+        if g.numel() == 0:
+            return gx, gres, None, None, None
         _lib.check(lib.adil_affine_act_bwd(_ptr(g), _ptr(y), _ptr(scale), _ptr(gx), _ptr(gres), g.numel(), g.shape[1], inner,
                                            int(relu), stream_dtype_code(g.dtype), _stream()), "adil_affine_act_bwd")
         return gx, gres, None, None, None
@@ -405,8 +409,10 @@ class PointwiseConvFunction(torch.autograd.Function):
             if not r2.is_contiguous():
                 r2 = r2.contiguous()
         y = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device)
-        _lib.check(lib.adil_pw_conv_fwd(_ptr(x2), _ptr(w2d), _ptr(scale), _ptr(shift), _ptr(r2), _ptr(y), b * h * w, cin, cout,
-                                        int(relu), _ptr(pscale), _ptr(pshift), sub_w, sub_hw, _stream()), "adil_pw_conv_fwd")
+        if b > 0:                                                     # empty batches pass through like plain torch modules
+            _lib.check(lib.adil_pw_conv_fwd(_ptr(x2), _ptr(w2d), _ptr(scale), _ptr(shift), _ptr(r2), _ptr(y), b * h * w, cin,
+                                            cout, int(relu), _ptr(pscale), _ptr(pshift), sub_w, sub_hw, _stream()),
+                       "adil_pw_conv_fwd")
         if pscale is not None and sub_w:
             raise RuntimeError("prologue and stride-2 gather are not combined")
         ctx.save_for_backward(y if relu else None, scale, wt2d, x2 if pscale is not None else None, pscale, pshift)
@@ -445,6 +451,8 @@ class PointwiseConvFunction(torch.autograd.Function):
                 raise RuntimeError("stride-2 gradient does not match an even full-resolution grid")
         gx = torch.empty((b, h, w, cin), dtype=torch.bfloat16, device=g2.device)
         gres = torch.empty_like(g2) if has_res else None
+        if b == 0:
+            return (gx.permute(0, 3, 1, 2), gres.permute(0, 3, 1, 2) if has_res else None) + (None,) * 9
         _lib.check(lib.adil_pw_conv_bwd(_ptr(g2), _ptr(gt), _ptr(y), _ptr(scale), _ptr(wt2d), _ptr(gx), _ptr(gres), b * h * w,
                                         cin, cout, int(relu), _ptr(xin), _ptr(pscale), _ptr(pshift), _ptr(g3), sub_w, sub_hw,
                                         _stream()), "adil_pw_conv_bwd")
@@ -484,7 +492,8 @@ class Conv3x3Function(torch.autograd.Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         y = torch.empty((b, h, w, n), dtype=torch.bfloat16, device=x.device)
-        _lib.check(lib.adil_conv3x3(_ptr(x2), _ptr(wp_fwd), _ptr(y), b, h, w, c, n, _stream()), "adil_conv3x3")
+        if b > 0:
+            _lib.check(lib.adil_conv3x3(_ptr(x2), _ptr(wp_fwd), _ptr(y), b, h, w, c, n, _stream()), "adil_conv3x3")
         ctx.save_for_backward(wp_bwd)
         ctx.meta = (c,)
         return y.permute(0, 3, 1, 2)
@@ -499,7 +508,8 @@ class Conv3x3Function(torch.autograd.Function):
             g2 = g2.to(torch.bfloat16).contiguous()
         b, h, w, n = g2.shape
         gx = torch.empty((b, h, w, c), dtype=torch.bfloat16, device=g2.device)
-        _lib.check(lib.adil_conv3x3(_ptr(g2), _ptr(wp_bwd), _ptr(gx), b, h, w, n, c, _stream()), "adil_conv3x3")
+        if b > 0:
+            _lib.check(lib.adil_conv3x3(_ptr(g2), _ptr(wp_bwd), _ptr(gx), b, h, w, n, c, _stream()), "adil_conv3x3")
         return gx.permute(0, 3, 1, 2), None, None
 
 
@@ -538,6 +548,9 @@ class StemFunction(torch.autograd.Function):
         oh, ow = h // 2, w // 2
         ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
         y1 = torch.empty((b, oh, ow, 64), dtype=torch.bfloat16, device=x.device)
+        if b == 0:                                                    # empty batches pass through like plain torch modules
+            ctx.meta = (0, h, w, x.dtype, tuple(inv_std))
+            return torch.empty((0, ph, pw, 64), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
         _lib.check(lib.adil_stem_conv_fwd(_ptr(x), stream_dtype_code(x.dtype), _ptr(w_fwd), *mean, *inv_std, _ptr(scale),
                                           _ptr(shift), _ptr(y1), b, h, w, _stream()), "adil_stem_conv_fwd")
         p = torch.empty((b, ph, pw, 64), dtype=torch.bfloat16, device=x.device)
@@ -550,8 +563,10 @@ class StemFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        p, idx, w_bwd, scale = ctx.saved_tensors
         b, h, w, xdtype, inv_std = ctx.meta
+        if b == 0:
+            return (torch.empty((0, 3, h, w), dtype=xdtype, device=g.device),) + (None,) * 6
+        p, idx, w_bwd, scale = ctx.saved_tensors
         oh, ow = h // 2, w // 2
         g = g.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()   # NHWC (a no-op for channels_last gradients)
         gy = torch.empty((b, oh, ow, 64), dtype=torch.bfloat16, device=g.device)

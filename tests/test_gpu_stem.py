@@ -286,3 +286,13 @@ def test_pointwise_conv_stride2_gather_and_compact_gradient(b, oh, ow, k, n):
     gref = (v * sc2).bfloat16().float() @ wt.float().t()
     gerr = (gx.float() - gref).abs()
     assert bool((gerr <= 2 ** -6 * gref.abs() + 3e-2).all()) and float(gerr.mean()) < 4e-3
+
+
+def test_fused_resnet_accepts_empty_batch():
+    """An empty batch (performance.py's correctly-classified filter can leave none) passes through the fused classifier
+    like it does through plain torch modules."""
+    from dl_attack_on_imagenet_amd import zoo
+    m = zoo.build_classifier("resnet50", num_classes=10, seed=1, device=DEV, dtype=torch.bfloat16, channels_last=True,
+                             fuse_bn_act=True, fuse_stem=True)
+    out = m(torch.zeros(0, 3, 64, 64, device=DEV, dtype=torch.bfloat16))
+    assert out.shape == (0, 10)
