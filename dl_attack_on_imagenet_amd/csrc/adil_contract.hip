@@ -421,17 +421,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
     E* sd = reinterpret_cast<E*>(smem_raw);
     const int Ks = Kp + M::PAD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
-#ifdef SYNTH_XCD_REMAP
-    // workgroups are dealt round-robin to the 8 XCDs: give each XCD one contiguous range of tiles
-    int bid = blockIdx.x;
-    {
-        const int n = gridDim.x, per = n >> 3, full = per << 3;
-        if (bid < full) bid = (bid & 7) * per + (bid >> 3);
-    }
-    const int p0 = (tile0 + bid) * SYNTH_TILE;
-#else
+    // consecutive tiles go to consecutive workgroups, i.e. round-robin over the 8 XCDs: for this pure stream that is
+    // 8 % faster than giving each XCD one contiguous range of tiles (measured)
     const int p0 = (tile0 + blockIdx.x) * SYNTH_TILE;
-#endif
     if constexpr (FAST) {
         // D slice -> LDS.  The slice (128 pixels x K atoms) is one contiguous, 16-byte aligned run of 32*K float4:
         // every thread issues up to 8 independent 16-byte loads before the first conversion, so the fill costs ONE
