@@ -30,8 +30,8 @@ namespace {
 #define PW_LS (PW_BK + 8)              // LDS row stride (elements): 144 B = 9 x 16 B
 #define PW_PK 512                      // most input channels a fused prologue / backward epilogue supports
 
-template <int BN, bool PRO>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRO && BN == 128 ? 2 : 3))) void pw_conv_fwd_kernel(
+template <int BN, bool PRO, bool RES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRO && BN == 128 ? 2 : (RES ? 3 : 4)))) void pw_conv_fwd_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ wgt, const float* __restrict__ scale,
     const float* __restrict__ shift, const bf16_t* __restrict__ res, bf16_t* __restrict__ y, int M, int K, int N,
     int relu, int MT, int NT, const float* __restrict__ pscale, const float* __restrict__ pshift, int sub_w, int sub_hw) {
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRO && BN =
 
     load_tiles(0);
     // the residual does not depend on the GEMM: its loads fly under the whole K loop
-    u32x2 rr[CT][4];
-    if (res != nullptr) {
+    u32x2 rr[RES ? CT : 1][4];
+    if (RES) {
         const bf16_t* rp = res + (size_t)(mok ? m : M - 1) * N + n0 + 4 * h;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRO && BN =
             const f32x2* sh = reinterpret_cast<const f32x2*>(ssc + BN + co);
             f32x2 v0 = f32x2{acc[ct][4 * q], acc[ct][4 * q + 1]} * sc[0] + sh[0];
             f32x2 v1 = f32x2{acc[ct][4 * q + 2], acc[ct][4 * q + 3]} * sc[1] + sh[1];
-            if (res != nullptr) {
+            if (RES) {
                 v0 += bf2_to_f32x2(rr[ct][q][0]);
                 v1 += bf2_to_f32x2(rr[ct][q][1]);
             }
@@ -366,22 +366,31 @@ int launch_pw_bwd(const void* g, const void* g2, const void* y, const float* sca
     return 0;
 }
 
-template <int BN, bool PRO>
-int launch_pw_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res, void* y, int M,
+template <int BN, bool PRO, bool RES>
+int launch_pw_fwd_r(const void* x, const void* w, const float* scale, const float* shift, const void* res, void* y, int M,
                   int K, int N, int relu, const float* pscale, const float* pshift, int sub_w, int sub_hw, hipStream_t st) {
     const int MT = (M + PW_BM - 1) / PW_BM, NT = N / BN;
     const size_t tiles = (size_t)(PW_BM + BN) * PW_LS * sizeof(bf16_t);
     const size_t outb = (size_t)4 * 32 * (BN + 8) * sizeof(bf16_t);
     const size_t lds = tiles > outb ? tiles : outb;
     if (lds > 48 * 1024) {
-        const hipError_t e = hipFuncSetAttribute((const void*)pw_conv_fwd_kernel<BN, PRO>,
+        const hipError_t e = hipFuncSetAttribute((const void*)pw_conv_fwd_kernel<BN, PRO, RES>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((pw_conv_fwd_kernel<BN, PRO>), dim3((unsigned)(MT * NT)), dim3(256), lds, st, (const bf16_t*)x,
+    hipLaunchKernelGGL((pw_conv_fwd_kernel<BN, PRO, RES>), dim3((unsigned)(MT * NT)), dim3(256), lds, st, (const bf16_t*)x,
                        (const bf16_t*)w, scale, shift, (const bf16_t*)res, (bf16_t*)y, M, K, N, relu, MT, NT, pscale, pshift, sub_w, sub_hw);
     ADIL_CHECK_LAUNCH();
     return 0;
+}
+
+template <int BN, bool PRO>
+int launch_pw_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* res, void* y, int M,
+                  int K, int N, int relu, const float* pscale, const float* pshift, int sub_w, int sub_hw, hipStream_t st) {
+    // without a residual the 32 registers of its prefetch are free: 4 workgroups per CU instead of 3
+    if (res != nullptr)
+        return launch_pw_fwd_r<BN, PRO, true>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, sub_w, sub_hw, st);
+    return launch_pw_fwd_r<BN, PRO, false>(x, w, scale, shift, res, y, M, K, N, relu, pscale, pshift, sub_w, sub_hw, st);
 }
 
 }  // namespace
