@@ -1,5 +1,6 @@
 // adil_convs.hip — the frozen ResNet's convolutions behind the stem, on channels_last bf16 storage (gfx950):
-//   pw_conv_fwd / pw_conv_bwd   1x1 / stride-1 convolutions as GEMMs with the BatchNorm / residual / ReLU epilogue (and
+//   pw_conv_fwd / pw_conv_bwd   1x1 convolutions (stride 1, and the stride-2 downsample ones through an in-kernel
+//                               gather) as GEMMs with the BatchNorm / residual / ReLU epilogue (and
 //                               the previous layer's BatchNorm + ReLU as a prologue) applied on chip, forward and input
 //                               gradient
 //   conv3x3                     3x3 / stride-1 convolutions as an implicit GEMM with linear pixel tiling
@@ -18,7 +19,8 @@
 // and at ResNet-50 / B = 512 it is HBM-bound (K <= 2048, activations of 0.1 - 0.8 GB): what matters is that every
 // activation crosses HBM once.  A library GEMM + a separate epilogue kernel writes and re-reads the pre-activation
 // tensor (the epilogue passes were 10.5 ms of a 51 ms step); here the epilogue runs on the accumulators.
-//   Workgroup = 128 pixels x BN channels (BN = 128 or 64), K in chunks of 64 through double-buffered LDS.
+//   Workgroup = 128 pixels x BN channels (BN = 128 or 64), K in chunks of 64 through LDS (the next chunk waits in
+//   registers: one 37 KB buffer, 3-4 workgroups per CU).
 //   MFMA roles as in the stem: A = W (rows = channels -> accumulator registers), B = X (columns = pixels -> lanes),
 //   so a lane owns 4 consecutive channels of one pixel per register quad (8-byte residual loads); the finished tile
 //   goes through a per-wave LDS transpose to 16-byte NHWC stores.
