@@ -31,6 +31,10 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=100)
     p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--mode", default="learn", choices=["learn", "inference"],
+                   help="learn: one step = the loop body of learn_dictionary_a (the headline, configs[1]); inference: one "
+                        "step = one iteration of forward_supervised_DDrague over the batch (the attack(x, y) path that "
+                        "transfer evaluation, configs[3], runs)")
     p.add_argument("--model", default="resnet50")
     p.add_argument("--batch", type=int, default=512, help="images per GPU (weak scaling)")
     p.add_argument("--atoms", type=int, default=50)
@@ -51,18 +55,20 @@ def parse_args():
     p.add_argument("--cache-labels", type=int, default=0,
                    help="1: compute the (constant) clean pseudo-labels once instead of every step (reference quirk Q4)")
     p.add_argument("--cpu-baseline", type=int, default=1)
-    p.add_argument("--cpu-batch", type=int, default=16)
-    p.add_argument("--cpu-steps", type=int, default=2)
+    p.add_argument("--cpu-batch", type=int, default=32, help="images of the config-2-shape CPU sample")
+    p.add_argument("--cpu-steps", type=int, default=1)
+    p.add_argument("--cpu-config1", type=int, default=1, help="also run configs[0] (resnet18, 32 images, 10 atoms, 20 "
+                                                              "iterations, fp32) in full on the host cores and on the GPU")
     return p.parse_args()
 
 
 class KernelTimer:
     """Brackets every launch group of the hand-written kernels with HIP events on the launch stream."""
 
-    GROUPS = ("pack_codes", "synth", "grad", "adamw_clamp_", "adamw_l1ball_")
+    GROUPS = ("pack_codes", "synth", "grad", "adamw_clamp_", "adamw_l1ball_", "zstep_")
 
     def __init__(self, ops):
-        self.ops, self.enabled, self.records, self.empty = ops, False, {g: [] for g in self.GROUPS}, []
+        self.ops, self.enabled, self.records, self.empty = ops, False, {}, []
         for name in self.GROUPS:
             setattr(ops, name, self._wrap(name, getattr(ops, name)))
 
@@ -70,11 +76,14 @@ class KernelTimer:
         def timed(*a, **k):
             if not self.enabled:
                 return fn(*a, **k)
+            key = name
+            if name == "grad" and a[0].dtype == torch.float32 and not k.get("want_d", True):
+                key = "grad[z D_dagger^T]"                        # the fp32-z contraction of the DDrague iteration
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = fn(*a, **k)
             e1.record()
-            self.records[name].append((e0, e1))
+            self.records.setdefault(key, []).append((e0, e1))
             if name == "synth":                                  # an EMPTY bracket, recorded the same way on the same
                 c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # stream: what
                 c0.record()                                      # two back-to-back event markers cost by themselves
@@ -98,8 +107,16 @@ class KernelTimer:
         return out
 
 
-def algorithmic_bytes(B, P, K, N, s):
+def algorithmic_bytes(B, P, K, N, s, mode="learn"):
     """Per launch group, SURVEY.md §8(d): s = bytes/element of the image streams, D / V master fp32."""
+    if mode == "inference":                                        # one DDrague iteration: 7*B*P*4 + 3*B*P*s + 4*P*K*4
+        return {
+            "grad[z D_dagger^T]": B * P * 4 + P * K * 4 + B * K * 4,   # read z (fp32), read D_dagger, write codes
+            "synth": 2 * B * P * s + P * K * 4 + B * K * 4,            # read x, write x + D v, read D
+            "grad": B * P * s + P * K * 4 + B * K * 4,                 # read g, read D, write dL/dv
+            "zstep_": 6 * B * P * 4 + P * K * 4 + B * K * 4,           # z, m, s read + written; D_dagger; dL/dv
+            "pack_codes": 2 * B * K * 4,
+        }
     return {
         "synth": 2 * B * P * s + P * K * 4 + B * K * 4,            # read x, write x+Dv, read D (+ codes)
         "grad": B * P * s + P * K * 4 + P * K * 4 + B * K * 8,     # read g, read D, write grad_d (+ codes, grad_v)
@@ -109,8 +126,66 @@ def algorithmic_bytes(B, P, K, N, s):
     }
 
 
-def cpu_baseline(args, P_shape):
-    """The oracle's learn_step_a (op-for-op the reference's sequence) on the host cores, bounded sample."""
+def _config1_problem():
+    """BASELINE.json configs[0] / BASELINE.md §3: resnet18, N = B = 32 images of 3x224x224, 10 atoms, 20 iterations, fp32,
+    eps 8/255, lr 0.01, kappa 50, loss 'logits'; seeded synthetic inputs."""
+    from oracle import adil_oracle as O
+    g = torch.Generator().manual_seed(21)
+    n, k, eps = 32, 10, 8 / 255
+    images = torch.rand(n, 3, 224, 224, generator=g)
+    d0 = -1 + 2 * torch.rand(3, 224, 224, k, generator=g)
+    v0 = O.project_onto_l1_ball(torch.rand(n, k, generator=g), eps)
+    return images, d0, v0, eps
+
+
+def cpu_config1(dev):
+    """configs[0] in full: the CPU oracle on the host cores, and the HIP path on the same inputs and seeds; per-iteration
+    fooled counts and the final attack success rate (performance.py:238-246) of both."""
+    from oracle import adil_oracle as O
+    from dl_attack_on_imagenet_amd import engine, zoo
+    images, d0, v0, eps = _config1_problem()
+    n, T = images.shape[0], 20
+    index = torch.arange(n)
+    cpu_model = zoo.build_classifier("resnet18", seed=5)
+    d, v = d0.clone(), v0.clone()
+    od, ov = O.AdamWState(d, 0.01), O.AdamWState(v, 0.01)
+    fooled_cpu = []
+    t0 = time.perf_counter()
+    for _ in range(T):
+        _, fl = O.learn_step_a(cpu_model, images, index, d, v, od, ov, eps, "logits", -1.0, 50.0)
+        fooled_cpu.append(int(fl))
+    cpu_s = time.perf_counter() - t0
+    with torch.no_grad():
+        adv = images + (v @ d.reshape(-1, d.shape[-1]).t()).reshape(images.shape)
+        asr_cpu = float((cpu_model(adv).argmax(-1) != cpu_model(images).argmax(-1)).float().mean())
+    gpu_model = zoo.build_classifier("resnet18", seed=5, device=dev)
+    learner = engine.DictionaryLearner(d0.to(dev), v0.to(dev), eps, 0.01, "logits", False, 50.0)
+    x, idx = images.to(dev), index.to(dev)
+    fooled_gpu = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(T):
+        _, fl = learner.step(gpu_model, x, idx)
+        fooled_gpu.append(fl)
+    torch.cuda.synchronize()
+    gpu_s = time.perf_counter() - t0
+    fooled_gpu = [int(f) for f in fooled_gpu]
+    with torch.no_grad():
+        vp = engine.ops.pack_codes(learner.v, None, n)
+        adv = engine.ops.synth(x, learner.d, vp, n)
+        asr_gpu = float((gpu_model(adv).argmax(-1) != gpu_model(x).argmax(-1)).float().mean())
+    return {"workload": "configs[0]: resnet18, 32 images 3x224x224, 10 atoms, 20 iterations, fp32, in full",
+            "cpu_images_per_sec": n * T / cpu_s, "cpu_seconds": cpu_s, "gpu_images_per_sec": n * T / gpu_s,
+            "gpu_seconds": gpu_s, "asr_cpu": asr_cpu, "asr_gpu": asr_gpu, "fooled_per_iteration_cpu": fooled_cpu,
+            "fooled_per_iteration_gpu": fooled_gpu}
+
+
+def cpu_baseline(args, P_shape, dev):
+    """The oracle (op-for-op the reference's sequence) on the host cores, bounded sample of the bench workload:
+    configs[1] shape (same classifier, atoms, image size, loss) on `--cpu-batch` of its images — images/sec is a
+    per-image rate, so the sample scales to the full batch linearly in everything except the AdamW pass over D
+    (7*P*K*4 bytes per step, independent of the batch).  Plus configs[0] in full with the ASR of both
+    paths on the same inputs."""
     from oracle import adil_oracle as O
     from dl_attack_on_imagenet_amd import zoo
     threads = torch.get_num_threads()
@@ -119,30 +194,65 @@ def cpu_baseline(args, P_shape):
     g = torch.Generator().manual_seed(0)
     x = torch.rand(b, *P_shape, generator=g)
     d = -1 + 2 * torch.rand(*P_shape, k, generator=g)
-    v = O.project_onto_l1_ball(torch.rand(b, k, generator=g), 8 / 255)
-    od, ov = O.AdamWState(d, 0.01), O.AdamWState(v, 0.01)
-    index = torch.arange(b)
-    O.learn_step_a(model, x, index, d, v, od, ov, 8 / 255, args.loss, -1.0, 50.0)      # warm-up (allocators, MKL)
-    t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
-        O.learn_step_a(model, x, index, d, v, od, ov, 8 / 255, args.loss, -1.0, 50.0)
-    dt = time.perf_counter() - t0
-    return {"value": b * args.cpu_steps / dt, "unit": "adversarial images/sec", "cores": threads, "kind": "port",
-            "sample": f"{args.cpu_steps} learning steps of the CPU oracle (oracle/adil_oracle.py learn_step_a, fp32, "
-                      f"torch {torch.__version__} CPU, {threads} threads of {os.cpu_count()} logical cores), "
-                      f"{args.model}, batch {b}, {k} atoms, {P_shape[1]}x{P_shape[2]} images; {dt:.1f} s"}
+    if args.mode == "inference":
+        O.forward_supervised_ddrague(model, x[:2], d, 8 / 255, 1, args.loss)            # warm-up (allocators, MKL)
+        iters = max(2, args.cpu_steps)
+        t0 = time.perf_counter()
+        O.forward_supervised_ddrague(model, x, d, 8 / 255, iters, args.loss)
+        dt = time.perf_counter() - t0
+        what = (f"{iters} iterations of the CPU oracle's forward_supervised_ddrague (incl. the once-per-call Gram / "
+                f"pseudo-inverse)")
+        value = b * iters / dt
+    else:
+        v = O.project_onto_l1_ball(torch.rand(b, k, generator=g), 8 / 255)
+        od, ov = O.AdamWState(d, 0.01), O.AdamWState(v, 0.01)
+        index = torch.arange(b)
+        O.learn_step_a(model, x[:2], index[:2], d, v, od, ov, 8 / 255, args.loss, -1.0, 50.0)   # warm-up
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_steps):
+            O.learn_step_a(model, x, index, d, v, od, ov, 8 / 255, args.loss, -1.0, 50.0)
+        dt = time.perf_counter() - t0
+        what = f"{args.cpu_steps} learning step(s) of the CPU oracle (oracle/adil_oracle.py learn_step_a)"
+        value = b * args.cpu_steps / dt
+    out = {"value": value, "unit": "adversarial images/sec", "cores": threads, "kind": "port",
+           "sample": f"{what}, fp32, torch {torch.__version__} CPU, {threads} threads of {os.cpu_count()} logical "
+                     f"cores; configs[1] shape ({args.model}, {k} atoms, {P_shape[1]}x{P_shape[2]}) on {b} of its "
+                     f"{args.batch} images per step; {dt:.1f} s"}
+    if args.cpu_config1 and args.mode == "learn":
+        out["config1"] = cpu_config1(dev)
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves.  This parent has
+    made no GPU call (importing torch does not initialise HIP) and never will: the ranks are fresh child processes
+    of `python -m torch.distributed.run`, one per GPU, rendezvous on 127.0.0.1; rank 0 prints the JSON line, which
+    passes through on the inherited stdout; the parent exits with the launcher's return code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     from dl_attack_on_imagenet_amd import dist as adist
     rank, world, local_rank = adist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ADiL hot path has no CPU fallback")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", adist.local_device_index(local_rank))
+    torch.cuda.set_device(dev)
 
     from dl_attack_on_imagenet_amd import engine, ops, zoo
     timer = KernelTimer(ops)
@@ -166,12 +276,19 @@ def main():
     # ADIL_FORCE_REDUCER=1 exercises the RCCL path (process group, all-reduce of grad_d) even with one rank
     force = os.environ.get("ADIL_FORCE_REDUCER") == "1" and torch.distributed.is_initialized()
     reducer = adist.DictGradReducer() if (world > 1 or force) else None
-    learner = engine.DictionaryLearner(d, v, eps, 0.01, args.loss, False, 50.0, reducer=reducer)
-    index = torch.arange(B, device=dev)
-    labels = engine.predict(model, x) if args.cache_labels else None
+    if args.mode == "inference":
+        solver = engine.DDragueSolver(model, x, d, eps, args.loss, False, 50.0)          # Gram / pseudo-inverse: once per call
 
-    def step():
-        return learner.step(model, x, index, labels)
+        def step():
+            solver.iterate()                                  # no host sync: the stop test is left to the caller
+            return None, None
+    else:
+        learner = engine.DictionaryLearner(d, v, eps, 0.01, args.loss, False, 50.0, reducer=reducer)
+        index = torch.arange(B, device=dev)
+        labels = engine.predict(model, x) if args.cache_labels else None
+
+        def step():
+            return learner.step(model, x, index, labels)
 
     def sync():
         torch.cuda.synchronize()
@@ -195,9 +312,13 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax)
 
-    fool_rate = float(fooled) / B
+    if args.mode == "inference":
+        adv, _ = solver.result()
+        fool_rate = float((engine.predict(model, adv) != solver.labels).float().mean())
+    else:
+        fool_rate = float(fooled) / B
     kern_ms = timer.summary_ms()
-    alg = algorithmic_bytes(B, P, K, B, s_bytes)
+    alg = algorithmic_bytes(B, P, K, B, s_bytes, args.mode)
     dom = max((k for k in kern_ms if k in alg), key=lambda k: kern_ms[k])
     achieved = alg[dom] / (kern_ms[dom] * 1e-3) / 1e9
     traffic = None
@@ -209,16 +330,21 @@ def main():
             traffic = None
     dict_ms = sum(kern_ms.values())
     out = {
-        "metric": "adversarial images/sec (ADiL learning step, classifier included)",
+        "metric": "adversarial images/sec (ADiL learning step, classifier included)" if args.mode == "learn" else
+                  "adversarial images/sec (ADiL DDrague inference iteration, classifier included)",
         "value": world * B * args.steps / elapsed,
         "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"ADiL learn_dictionary_a step vs {args.model}, {B} images/GPU, {K} atoms, "
-                               f"{S}x{S}, {args.dtype} image streams + fp32 D/V master, loss={args.loss}, "
-                               f"{'cached' if args.cache_labels else 'recomputed'} pseudo-labels (2 fwd + 1 bwd)",
+        "config": {"workload": (f"ADiL learn_dictionary_a step vs {args.model}, {B} images/GPU, {K} atoms, "
+                                f"{S}x{S}, {args.dtype} image streams + fp32 D/V master, loss={args.loss}, "
+                                f"{'cached' if args.cache_labels else 'recomputed'} pseudo-labels (2 fwd + 1 bwd)")
+                   if args.mode == "learn" else
+                   (f"ADiL forward_supervised_DDrague iteration (the attack(x, y) path of transfer evaluation) vs "
+                    f"{args.model}, {B} images/GPU, {K} atoms, {S}x{S}, {args.dtype} image streams, fp32 z + AdamW "
+                    f"moments, loss={args.loss}, clean labels computed once (constant; 1 fwd + 1 bwd per iteration)"),
                    "classifier": f"random-init {args.model}, frozen, eval; channels_last={args.channels_last}, "
                                  f"bn_act_epilogue_fused={args.fuse_bn_act}, bn_folded={args.fold_bn}, "
                                  f"first_conv_cin_padded_to={args.pad_cin} (unused with stem kernels), stem_kernels={args.fuse_stem}, "
@@ -226,7 +352,7 @@ def main():
                                  f"stride1_3x3_convs=adil_conv3x3",
                    "global_batch": world * B, "atoms": K, "inner_iters": args.steps,
                    "parallelism": f"dp{world}: images+codes sharded, D replicated, 1 all-reduce(grad_d)/step",
-                   "train_fooling_rate_last_step": fool_rate},
+                   ("train_fooling_rate_last_step" if args.mode == "learn" else "fooling_rate_after_timed_iterations"): fool_rate},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern_ms[dom],
@@ -236,7 +362,7 @@ def main():
         "dictionary_path_algorithmic_GBps": sum(alg[k] for k in kern_ms if k in alg) / (dict_ms * 1e-3) / 1e9,
     }
     if rank == 0 and world == 1 and args.cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, shape)
+        out["cpu_baseline"] = cpu_baseline(args, shape, dev)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():

@@ -46,7 +46,27 @@ def build_parser():
     return p
 
 
+def spawn_ranks(args):
+    """--distributed outside a torchrun environment: start one rank per visible GPU ourselves.  The parent makes no GPU
+    call (device_count() does not initialise HIP on this stack); the ranks are fresh children of torch.distributed.run.
+    Replaces the SLURM bootstrap of env_setting.py:10-28."""
+    import socket
+    import subprocess
+    import sys
+    n = torch.cuda.device_count()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={max(1, n)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main(args):
+    if args.distributed and "WORLD_SIZE" not in os.environ and torch.cuda.device_count() > 1:
+        raise SystemExit(spawn_ranks(args))
     if not torch.cuda.is_available():
         print('Check cuda setting for model training on ImageNet')       # demo_dL_attack.py:30-32
         return
@@ -57,7 +77,7 @@ def main(args):
         device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
         torch.cuda.set_device(device)
 
-    model_name = zoo.canonical_name(args.model)
+    model_name = args.model.lower()          # names the dictionary file, as upstream (demo_dL_attack.py:41, adil.py:89-91)
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     fast = bool(args.fast_classifier) and dtype == torch.bfloat16 and zoo.canonical_name(model_name).startswith('resnet')
     model = zoo.build_classifier(model_name, seed=args.seed, weights=args.weights, device=device, dtype=dtype,
@@ -86,13 +106,16 @@ def main(args):
     out_dir = 'dict_model_ImageNet_version_constrained'
     os.makedirs(out_dir, exist_ok=True)                                                   # quirk Q14: upstream assumes it exists
     print('Evaluation process')
+    writer = int(os.environ.get('RANK', '0')) == 0                                        # one writer under --distributed
     val_perf = perf.get_performance(attacks_hyper, model, _cast_loader(val_loader, dtype), device=device)
-    torch.save(val_perf, os.path.join(out_dir, f'model_sampling_adil_inference_rlts_sampling_'
-                                               f'{args.num_train_per_class * n_classes}_{args.steps_inference}_'
-                                               f'{args.seed}_ce.bin'))
+    if writer:                                                                            # demo_dL_attack.py:148-151
+        torch.save(val_perf, os.path.join(out_dir, f'model_sampling_adil_inference_rlts_sampling_'
+                                                   f'{args.num_train_per_class * args.trained_classes}_'
+                                                   f'{args.steps_inference}_{args.seed}_ce.bin'))
     print('Test process')
     test_perf = perf.get_performance(attacks_hyper, model, _cast_loader(test_loader, dtype), device=device)
-    torch.save(test_perf, os.path.join(out_dir, 'model_adil_resultat_test_ce.bin'))
+    if writer:                                                                            # demo_dL_attack.py:153-156
+        torch.save(test_perf, os.path.join(out_dir, 'model_adil_resultat_test_ce.bin'))
     return val_perf, test_perf
 
 

@@ -14,7 +14,9 @@ SIGNATURES = {
     "adil_abi_version": (c_int, []),
     "adil_max_atoms": (c_int, []),
     "adil_grad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "adil_pack_codes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "adil_pack_codes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "adil_gather_images": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "adil_spd_inverse": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "adil_synth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "adil_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                           c_size_t, c_void_p]),
@@ -22,7 +24,7 @@ SIGNATURES = {
                                  c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "adil_zstep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
                            c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
-    "adil_adamw_l1ball": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
+    "adil_adamw_l1ball": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
                                   c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "adil_l1ball_project": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     "adil_l2ball_project": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
@@ -51,7 +53,7 @@ SIGNATURES = {
                                    c_void_p]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

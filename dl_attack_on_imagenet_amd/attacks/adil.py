@@ -15,7 +15,8 @@ import torch
 import torch.nn as nn
 
 from .. import engine, ops
-from ..dist import DictGradReducer, init_from_env, shard_bounds
+from ..dist import DictGradReducer, global_epoch_batches, init_from_env, owned_rows, shard_bounds
+from ..loader import ResidentImages, shuffled_batches
 from .base import Attack
 from .utils import QuickAttackDataset, clamp_image, constraint_dict, project_onto_l1_ball  # noqa: F401
 
@@ -42,6 +43,12 @@ class Attack_dict_model(nn.Module):
         self.d.data.clamp_(min=-1, max=1)
 
 
+def engine_solve_codes(atk, images, d, mean_over=None):
+    """forward_supervised_AdamW in 'train' mode on one rank's shard of a validation batch."""
+    return engine.solve_codes_adamw(atk.model, images, d, atk.eps, atk.loss, atk.targeted, atk.kappa, atk.norm, 'train',
+                                    mean_over=mean_over)
+
+
 class ADIL(Attack):
     """ADiL — Adversarial Dictionary Learning (signature of adil.py:63-66).
 
@@ -54,13 +61,16 @@ class ADIL(Attack):
       epoch_batches, val_batches   explicit batch order instead of the shuffled DataLoader (tests / multi-GPU parity)
       stream_dtype   torch.float32 (default) or torch.bfloat16 for the image-shaped streams x+Dv and dLoss/dx
       dict_dir       folder of the dictionary file (default 'trained_dicts')
+      shuffle_seed   seed of the per-epoch global batches of the data-parallel learner (identical on every rank)
     """
+
+    _learner_cls = engine.DictionaryLearner      # the fused (D, V) update; tests of the host logic may inject another
 
     def __init__(self, model, eps=None, steps=5e2, norm='linf', targeted=False, n_atoms=100, batch_size=100,
                  data_train=None, data_val=None, trials=10, attack='supervised', model_name=None, step_size=0.01,
                  is_distributed=False, steps_in=None, loss='ce', method='gd', warm_start=False, kappa=50,
                  steps_inference=30, alpha=None, init_d=None, init_v=None, epoch_batches=None, val_batches=None,
-                 stream_dtype=None, dict_dir='trained_dicts'):
+                 stream_dtype=None, dict_dir='trained_dicts', shuffle_seed=0):
         super().__init__("ADIL", model.eval())
         self.norm = norm.lower()
         self.eps = eps
@@ -81,6 +91,7 @@ class ADIL(Attack):
         self.stream_dtype = stream_dtype
         self._init_d, self._init_v = init_d, init_v
         self._epoch_batches, self._val_batches = epoch_batches, val_batches
+        self._shuffle_seed = int(shuffle_seed)
         self._pinv = None
         self._dict_mtime = None
         self.model_file = os.path.join(dict_dir, f"ImageNet_{model_name}.bin")
@@ -89,7 +100,7 @@ class ADIL(Attack):
             if data_train is None:
                 return                           # nothing to learn from yet; forward() reports it
             if is_distributed:
-                self.learn_dictionary_distributed(data_train)
+                self.learn_dictionary_distributed(data_train, data_val)
             elif method == 'gd':
                 self.learn_dictionary_a(dataset=data_train, val=data_val, warm_start=warm_start)
             elif method == 'alter':
@@ -126,37 +137,25 @@ class ADIL(Attack):
             return self.projection_d(torch.randn(nc, nx, ny, self.n_atoms, device=self.device))
         return -1 + 2 * torch.rand(nc, nx, ny, self.n_atoms, device=self.device)   # adil.py:148
 
-    def _loader(self, dataset, batch_size, explicit):
-        if explicit is not None:
-            return None
-        return torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=True, pin_memory=True,
-                                           num_workers=0)
+    def _resident(self, dataset, rows=None):
+        """The data step in front of the path: the dataset (or this rank's rows of it) resident in HBM in the stream
+        dtype; replaces the per-item DataLoader of adil.py:130-133 (see loader.py)."""
+        return ResidentImages(dataset, self.device, self.stream_dtype or torch.float32, rows=rows)
 
     @staticmethod
-    def _explicit_batches(dataset, batches, indexed):
-        for idx in batches:
-            idx = [int(i) for i in idx]
-            xs = torch.stack([dataset[i][1] if indexed else dataset[i][0] for i in idx])
-            yield torch.as_tensor(idx, dtype=torch.int64), xs
+    def _epoch_order(n, batch_size, explicit, epoch):
+        """Index batches of one epoch: injected (tests / multi-GPU parity) or the reference's shuffled DataLoader order."""
+        if explicit is not None:
+            return [[int(i) for i in idx] for idx in explicit[epoch]]
+        return shuffled_batches(n, batch_size)
 
-    def _train_batches(self, dataset, loader, epoch):
-        if loader is None:
-            yield from self._explicit_batches(dataset, self._epoch_batches[epoch], True)
-        else:
-            for index, x, _ in loader:
-                yield index, x
-
-    def _validate(self, val, loader, epoch, d):
-        """Per-epoch validation through forward_supervised_AdamW in 'train' mode (adil.py:199-205)."""
+    def _validate(self, val, epoch, d, batch_size):
+        """Per-epoch validation through forward_supervised_AdamW in 'train' mode (adil.py:199-205).
+        `val` is a ResidentImages (or None)."""
         if val is None:
             return torch.zeros((), device=self.device)
         fooled = torch.zeros((), dtype=torch.int64, device=self.device)
-        if loader is None:
-            val.indexed = False
-            it = self._explicit_batches(val, self._val_batches[epoch], False)
-        else:
-            it = ((None, x) for x, _ in loader)
-        for _, x in it:
+        for _, x in val.batches(self._epoch_order(len(val), batch_size, self._val_batches, epoch)):
             fooled += self.forward_supervised_AdamW(x, None, d, 'train')
         return fooled / len(val)
 
@@ -173,28 +172,27 @@ class ADIL(Attack):
         """Joint AdamW learning of (D, V) — learn_dictionary_a (adil.py:114-210)."""
         n_img, shape = self._dataset_shape(dataset)
         batch_size = n_img if self.batch_size is None else self.batch_size
-        dataset.indexed = True
-        loader = self._loader(dataset, batch_size, self._epoch_batches)
-        val_loader = self._loader(val, batch_size, self._val_batches) if val is not None else None
+        train = self._resident(dataset)
+        val_res = self._resident(val) if val is not None else None
 
         d = self._initial_dictionary(shape, warm_start)
         v0 = self._init_v if self._init_v is not None else torch.rand(n_img, self.n_atoms, device=self.device)
         v = self.projection_v(v0.to(device=self.device, dtype=torch.float32))               # adil.py:150
-        learner = engine.DictionaryLearner(d, v, self.eps, self.step_size, self.loss, self.targeted, self.kappa)
+        learner = self._learner_cls(d, v, self.eps, self.step_size, self.loss, self.targeted, self.kappa)
 
         loss_all, fooling_rate_all = [], []
         val_fool = torch.zeros((), device=self.device)
         for iteration in range(int(self.steps)):
             loss_full = torch.zeros((), dtype=torch.float32, device=self.device)
             fooled = torch.zeros((), dtype=torch.int64, device=self.device)
-            for index, x in self._train_batches(dataset, loader, iteration):
-                ls, fl = learner.step(self.model, self._cast(x), index)                    # adil.py:168-191
+            for index, x in train.batches(self._epoch_order(n_img, batch_size, self._epoch_batches, iteration)):
+                ls, fl = learner.step(self.model, x, index)                                # adil.py:168-191
                 loss_full += ls
                 fooled += fl
             loss_all.append(loss_full.item() / n_img)                                      # adil.py:194
             fooling_rate_all.append(fooled.item() / n_img)                                 # adil.py:195
             print(loss_all[-1], fooling_rate_all[-1])
-            val_fool = self._validate(val, val_loader, iteration, learner.d)
+            val_fool = self._validate(val_res, iteration, learner.d, batch_size)
             print(float(val_fool))
             if iteration > 1 and abs(loss_all[iteration] - loss_all[iteration - 1]) < 1e-6:    # adil.py:207
                 break
@@ -206,80 +204,103 @@ class ADIL(Attack):
         step_size) then `steps_inner` epochs of D-steps (AdamW lr 2*step_size)."""
         n_img, shape = self._dataset_shape(dataset)
         batch_size = n_img if self.batch_size is None else self.batch_size
-        dataset.indexed = True
-        loader = self._loader(dataset, batch_size, self._epoch_batches)
-        val_loader = self._loader(val, batch_size, self._val_batches) if val is not None else None
+        train = self._resident(dataset)
+        val_res = self._resident(val) if val is not None else None
 
         d = self._initial_dictionary(shape, warm_start)
         v0 = self._init_v if self._init_v is not None else torch.zeros(n_img, self.n_atoms, device=self.device)
         v = self.projection_v(v0.to(device=self.device, dtype=torch.float32))               # adil.py:246
-        learner = engine.DictionaryLearner(d, v, self.eps, self.step_size, self.loss, self.targeted, self.kappa,
-                                           lr_d=2 * self.step_size, lr_v=self.step_size)    # adil.py:250-251
+        learner = self._learner_cls(d, v, self.eps, self.step_size, self.loss, self.targeted, self.kappa,
+                                    lr_d=2 * self.step_size, lr_v=self.step_size)           # adil.py:250-251
         loss_all, fooling_rate_all = [], []
         val_fool = torch.zeros((), device=self.device)
         epoch = 0
         for iteration in range(int(self.steps // self.steps_inner)):
             for _ in range(self.steps_inner):                                              # V-steps, adil.py:265-289
-                for index, x in self._train_batches(dataset, loader, epoch):
-                    learner.step_codes(self.model, self._cast(x), index)
+                for index, x in train.batches(self._epoch_order(n_img, batch_size, self._epoch_batches, epoch)):
+                    learner.step_codes(self.model, x, index)
                 epoch += 1
             for _ in range(self.steps_inner):                                              # D-steps, adil.py:292-314
                 fooled = torch.zeros((), dtype=torch.int64, device=self.device)
                 ls = None
-                for index, x in self._train_batches(dataset, loader, epoch):
-                    ls, fl = learner.step_dictionary(self.model, self._cast(x), index)
+                for index, x in train.batches(self._epoch_order(n_img, batch_size, self._epoch_batches, epoch)):
+                    ls, fl = learner.step_dictionary(self.model, x, index)
                     fooled += fl
                 epoch += 1
             loss_all.append(ls.item() / n_img)               # last batch only — reference quirk Q11 (adil.py:313-317)
             fooling_rate_all.append(fooled.item() / n_img)
             print('d_step: ', loss_all[-1], fooling_rate_all[-1])
-            val_fool = self._validate(val, val_loader, iteration, learner.d)
+            val_fool = self._validate(val_res, iteration, learner.d, batch_size)
             if iteration > 1 and abs(loss_all[iteration] - loss_all[iteration - 1]) < 1e-6:    # adil.py:329
                 break
         self._save(learner.d, learner.v, loss_all, fooling_rate_all, val_fool)
         return learner
 
-    def learn_dictionary_distributed(self, dataset):
-        """Data-parallel learn_dictionary_a: one process per GPU (torchrun env), this rank owns a contiguous
-        shard of the images and their code rows, D is replicated, and ONE all-reduce(SUM) of grad_d per step
-        keeps it bit-identical across ranks.  Replaces adil.py:334-430, which deadlocks as written (the loop
-        sits under `if rank == 0`); parity target = the single-process learner at the global batch."""
+    def learn_dictionary_distributed(self, dataset, val=None):
+        """Data-parallel learn_dictionary_a: one process per GPU (torchrun env).  Rank r OWNS a contiguous shard of the
+        images, keeps them resident in its HBM together with their code rows and AdamW moments; D is replicated.
+        Every step is one GLOBAL batch: each rank processes the members it owns, ONE all-reduce(SUM) of grad_d makes
+        the dictionary gradient the global batch's, and the identical fused AdamW keeps D bit-identical across ranks.
+        The global batches come from `epoch_batches` when injected, otherwise from dist.global_epoch_batches (seeded,
+        identical on all ranks, balanced); either way every rank takes the same number of steps — a rank that owns
+        nothing of a batch contributes a zero gradient — so collectives always pair up (ragged shards included).
+        Validation (adil.py:199-205) is sharded the same way and its fooled counts are summed.
+        Replaces adil.py:334-430, which deadlocks as written (the loop sits under `if rank == 0`); the parity target
+        is the single-process learner at the global batch."""
         rank, world, local_rank = init_from_env()
-        if world == 1:
-            return self.learn_dictionary_a(dataset, None, False)
+        if not torch.distributed.is_initialized():
+            return self.learn_dictionary_a(dataset, val, False)
         reducer = DictGradReducer()
         n_img, shape = self._dataset_shape(dataset)
+        batch_size = n_img if self.batch_size is None else self.batch_size
         lo, hi = shard_bounds(n_img, rank, world)
-        local = torch.utils.data.Subset(dataset, range(lo, hi))
-        local_bs = max(1, (n_img if self.batch_size is None else self.batch_size) // world)
-        dataset.indexed = True
-        gen = torch.Generator().manual_seed(1234 + rank)
-        loader = torch.utils.data.DataLoader(local, batch_size=local_bs, shuffle=True, generator=gen, num_workers=0)
+        train = self._resident(dataset, rows=range(lo, hi))
+        val_res, vlo, vhi = None, 0, 0
+        if val is not None:
+            vlo, vhi = shard_bounds(len(val), rank, world)
+            val_res = self._resident(val, rows=range(vlo, vhi))
 
         d = self._initial_dictionary(shape, False)
         reducer.broadcast_(d, 0)                                                  # identical D0 on every rank
         v0 = self._init_v[lo:hi] if self._init_v is not None else torch.rand(hi - lo, self.n_atoms, device=self.device)
         v = self.projection_v(v0.to(device=self.device, dtype=torch.float32))
-        learner = engine.DictionaryLearner(d, v, self.eps, self.step_size, self.loss, self.targeted, self.kappa,
-                                           reducer=reducer)
+        learner = self._learner_cls(d, v, self.eps, self.step_size, self.loss, self.targeted, self.kappa,
+                                    reducer=reducer)
         loss_all, fooling_rate_all = [], []
+        val_fool = torch.zeros((), device=self.device)
         for iteration in range(int(self.steps)):
             loss_full = torch.zeros((), dtype=torch.float32, device=self.device)
             fooled = torch.zeros((), dtype=torch.int64, device=self.device)
-            for index, x, _ in loader:
-                ls, fl = learner.step(self.model, self._cast(x), index - lo)
+            if self._epoch_batches is not None:
+                order = self._epoch_batches[iteration]
+            else:
+                order = global_epoch_batches(n_img, batch_size, world, self._shuffle_seed, iteration)
+            local = [[i - lo for i in owned_rows(gb, lo, hi)] for gb in order]
+            for index, x in train.batches(local):
+                ls, fl = learner.step(self.model, x, index)
                 loss_full += ls
                 fooled += fl
             tot_loss, tot_fooled = reducer.sum_scalars(loss_full, fooled)         # adil.py:418-419
             loss_all.append(tot_loss / n_img)
             fooling_rate_all.append(tot_fooled / n_img)
+            if rank == 0:
+                print(loss_all[-1], fooling_rate_all[-1])
+            if val_res is not None:
+                if self._val_batches is not None:
+                    vorder = self._val_batches[iteration]
+                else:
+                    vorder = global_epoch_batches(len(val), batch_size, world, self._shuffle_seed + 1, iteration)
+                vfooled = torch.zeros((), dtype=torch.int64, device=self.device)
+                for gb in vorder:
+                    mine = [i - vlo for i in owned_rows(gb, vlo, vhi)]
+                    vfooled += engine_solve_codes(self, val_res.gather(mine), learner.d, mean_over=len(gb))
+                val_fool = torch.tensor(reducer.sum_scalars(vfooled)[0] / len(val), device=self.device)
             if iteration > 1 and abs(loss_all[iteration] - loss_all[iteration - 1]) < 1e-6:
                 break
-        rows = [torch.empty(shard_bounds(n_img, r, world)[1] - shard_bounds(n_img, r, world)[0], self.n_atoms,
-                            device=self.device) for r in range(world)]
-        torch.distributed.all_gather(rows, learner.v)                            # once, at the end (not in the data path)
+        counts = [shard_bounds(n_img, r, world)[1] - shard_bounds(n_img, r, world)[0] for r in range(world)]
+        v_all = reducer.gather_rows(learner.v, counts)                           # once, at the end (not in the data path)
         if rank == 0:
-            self._save(learner.d, torch.cat(rows), loss_all, fooling_rate_all, torch.zeros(()))
+            self._save(learner.d, v_all, loss_all, fooling_rate_all, val_fool)
         torch.distributed.barrier()
         return learner
 

@@ -105,14 +105,19 @@ __device__ __forceinline__ void l1ball_row(float (&x)[EPL], int lane, float radi
 // ---- K5: AdamW on all N rows of V + l1-ball projection --------------------- //
 template <int EPL>
 __global__ __launch_bounds__(256) void adamw_l1ball_kernel(float* __restrict__ v, const float* __restrict__ grad_vb,
-                                                           const int32_t* __restrict__ pos, float* __restrict__ m,
+                                                           int32_t* __restrict__ pos, float* __restrict__ m,
                                                            float* __restrict__ s, int N, int K, AdamWHyper h,
-                                                           float radius, float* max_abs_delta, int do_adam) {
+                                                           float radius, float* max_abs_delta, int do_adam,
+                                                           int reset_pos) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= N) return;                          // whole wave exits together
     int slot = row;
-    if (pos != nullptr) slot = pos[row];
+    if (pos != nullptr) {
+        slot = pos[row];
+        // one wave owns the row: hand the slot table back all -1 for the next batch's adil_pack_codes
+        if (reset_pos && slot >= 0 && lane == 0) pos[row] = -1;
+    }
     float x[EPL], x_old[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
@@ -184,7 +189,8 @@ __global__ __launch_bounds__(256) void ista_kernel(float* __restrict__ v, const 
 
 // ---- gather + pad the batch's code rows ------------------------------------ //
 __global__ __launch_bounds__(256) void pack_codes_kernel(const float* __restrict__ v, const int64_t* __restrict__ index,
-                                                         int B, int K, int Kp, int Bp, float* __restrict__ vp) {
+                                                         int B, int K, int Kp, int Bp, float* __restrict__ vp,
+                                                         int32_t* __restrict__ pos) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Bp * Kp) return;
     const int b = i / Kp, k = i - b * Kp;
@@ -192,8 +198,69 @@ __global__ __launch_bounds__(256) void pack_codes_kernel(const float* __restrict
     if (b < B && k < K) {
         const int64_t row = (index != nullptr) ? index[b] : (int64_t)b;
         val = v[row * K + k];
+        if (k == 0 && pos != nullptr) pos[row] = b;     // batch slot of code row `row` (consumed + reset by K5)
     }
     vp[i] = val;
+}
+
+// ---- batched image gather (the data step in front of the path) -------------- //
+// dst[b][:] = convert(src[index[b]][:]); 8 elements per thread: 16-byte accesses on the 2-byte side, 2 x 16 B on the
+// 4-byte side.  P % 8 == 0.  One pass: B*P*(sizeof(S)+sizeof(D)) bytes.
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void gather_images_kernel(const S* __restrict__ src, const int64_t* __restrict__ index,
+                                                            D* __restrict__ dst, int B, int P8) {
+    const int b = blockIdx.y;
+    const int64_t row = (index != nullptr) ? index[b] : (int64_t)b;
+    const S* s = src + (size_t)row * P8 * 8;
+    D* d = dst + (size_t)b * P8 * 8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P8; i += gridDim.x * blockDim.x) {
+        float f[8];
+        if constexpr (sizeof(S) == 4) {
+            const float4 a = reinterpret_cast<const float4*>(s)[2 * i], c = reinterpret_cast<const float4*>(s)[2 * i + 1];
+            f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
+        } else {
+            const uint4 a = reinterpret_cast<const uint4*>(s)[i];
+            const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(w[j] << 16); f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+        }
+        if constexpr (sizeof(D) == 4) {
+            reinterpret_cast<float4*>(d)[2 * i] = make_float4(f[0], f[1], f[2], f[3]);
+            reinterpret_cast<float4*>(d)[2 * i + 1] = make_float4(f[4], f[5], f[6], f[7]);
+        } else {
+            uint4 o;
+            o.x = pack2_bf16(f[0], f[1]); o.y = pack2_bf16(f[2], f[3]); o.z = pack2_bf16(f[4], f[5]); o.w = pack2_bf16(f[6], f[7]);
+            reinterpret_cast<uint4*>(d)[i] = o;
+        }
+    }
+}
+
+// ---- K7: inverse of the K x K Gram matrix (symmetric positive definite) ------ //
+// One workgroup, in-place Gauss-Jordan without pivoting (stable for SPD matrices) on an fp64 copy in LDS: the result
+// is the correctly rounded fp32 inverse for any conditioning an fp32 LAPACK inverse can handle at all.
+__global__ __launch_bounds__(1024) void spd_inverse_kernel(const float* __restrict__ a, int K, float* __restrict__ out) {
+    extern __shared__ double inv_lds[];
+    double* A = inv_lds;                               // K x K
+    double* colk = inv_lds + (size_t)K * K;            // K: the pivot column before elimination
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < K * K; i += nt) A[i] = (double)a[i];
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        const double piv = 1.0 / A[k * K + k];
+        __syncthreads();
+        for (int i = tid; i < K; i += nt) colk[i] = A[i * K + k];
+        __syncthreads();
+        for (int j = tid; j < K; j += nt) A[k * K + j] = (j == k) ? piv : A[k * K + j] * piv;
+        __syncthreads();
+        for (int e = tid; e < K * K; e += nt) {
+            const int i = e / K, j = e - i * K;
+            if (i == k) continue;
+            const double f = colk[i];
+            A[e] = ((j == k) ? 0.0 : A[e]) - f * A[k * K + j];
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < K * K; i += nt) out[i] = (float)A[i];
 }
 
 // ---- K11: per-atom norms / scaling ------------------------------------------ //
@@ -327,16 +394,52 @@ static inline int stream_grid(size_t work_items, int per_block) {
     return (int)b;
 }
 
-extern "C" int adil_abi_version(void) { return 2; }
+extern "C" int adil_abi_version(void) { return 3; }
 extern "C" int adil_max_atoms(void) { return ADIL_MAX_ATOMS; }
 
-extern "C" int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, void* stream) {
+extern "C" int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, int32_t* pos,
+                               void* stream) {
     ADIL_ENTER();
     if (!v || !vp || B <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     const int Kp = round_up(K, 16), Bp = round_up(B, 32);
     const int total = Bp * Kp;
     hipLaunchKernelGGL(pack_codes_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, index, B, K,
-                       Kp, Bp, vp);
+                       Kp, Bp, vp, pos);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_gather_images(const void* src, int src_dtype, const int64_t* index, void* dst, int dst_dtype, int B,
+                                  int P, void* stream) {
+    ADIL_ENTER();
+    if (!src || !dst || B <= 0 || P <= 0 || (P & 7)) return ADIL_EINVAL;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return ADIL_EINVAL;
+    const int P8 = P / 8;
+    int gx = (P8 + 255) / 256;
+    if (gx > 64) gx = 64;
+    const dim3 grid(gx, B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_dtype == ADIL_F32 && dst_dtype == ADIL_F32)
+        hipLaunchKernelGGL((gather_images_kernel<float, float>), grid, block, 0, st, (const float*)src, index, (float*)dst, B, P8);
+    else if (src_dtype == ADIL_F32 && dst_dtype == ADIL_BF16)
+        hipLaunchKernelGGL((gather_images_kernel<float, bf16_t>), grid, block, 0, st, (const float*)src, index, (bf16_t*)dst, B, P8);
+    else if (src_dtype == ADIL_BF16 && dst_dtype == ADIL_F32)
+        hipLaunchKernelGGL((gather_images_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)src, index, (float*)dst, B, P8);
+    else if (src_dtype == ADIL_BF16 && dst_dtype == ADIL_BF16)
+        hipLaunchKernelGGL((gather_images_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)src, index, (bf16_t*)dst, B, P8);
+    else
+        return ADIL_EINVAL;
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_spd_inverse(const float* a, int K, float* out, void* stream) {
+    ADIL_ENTER();
+    if (!a || !out || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
+    const size_t lds = ((size_t)K * K + K) * sizeof(double);                 // K = 128: 132 096 B of the CU's 160 KB
+    hipError_t e = hipFuncSetAttribute((const void*)spd_inverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, a, K, out);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
@@ -361,33 +464,35 @@ extern "C" int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, 
     return 0;
 }
 
-static int launch_adamw_l1ball(float* v, const float* grad_vb, const int32_t* pos, float* m, float* s, int N, int K,
-                               AdamWHyper h, float radius, float* max_abs_delta, int do_adam, hipStream_t st) {
+static int launch_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, float* m, float* s, int N, int K,
+                               AdamWHyper h, float radius, float* max_abs_delta, int do_adam, int reset_pos,
+                               hipStream_t st) {
     const dim3 grid((N + 3) / 4), block(256);
     if (K <= 64)
         hipLaunchKernelGGL(adamw_l1ball_kernel<1>, grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
-                           max_abs_delta, do_adam);
+                           max_abs_delta, do_adam, reset_pos);
     else
         hipLaunchKernelGGL(adamw_l1ball_kernel<2>, grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
-                           max_abs_delta, do_adam);
+                           max_abs_delta, do_adam, reset_pos);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int adil_adamw_l1ball(float* v, const float* grad_vb, const int32_t* pos, float* m, float* s, int N, int K,
-                                 float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt,
+extern "C" int adil_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, int reset_pos, float* m, float* s, int N,
+                                 int K, float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt,
                                  float radius, float* max_abs_delta, void* stream) {
     ADIL_ENTER();
-    if (!v || !grad_vb || !m || !s || N <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
+    if (!v || !m || !s || N <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
+    if (!grad_vb && !pos) return ADIL_EINVAL;      // without a slot table every row reads its own gradient row
     AdamWHyper h{decay, b1, b2, eps, step_size, bc2_sqrt};
-    return launch_adamw_l1ball(v, grad_vb, pos, m, s, N, K, h, radius, max_abs_delta, 1, (hipStream_t)stream);
+    return launch_adamw_l1ball(v, grad_vb, pos, m, s, N, K, h, radius, max_abs_delta, 1, reset_pos, (hipStream_t)stream);
 }
 
 extern "C" int adil_l1ball_project(float* x, int N, int K, float radius, void* stream) {
     ADIL_ENTER();
     if (!x || N <= 0 || K <= 0 || K > ADIL_MAX_ATOMS || radius < 0.0f) return ADIL_EINVAL;
     AdamWHyper h{};
-    return launch_adamw_l1ball(x, nullptr, nullptr, nullptr, nullptr, N, K, h, radius, nullptr, 0, (hipStream_t)stream);
+    return launch_adamw_l1ball(x, nullptr, nullptr, nullptr, nullptr, N, K, h, radius, nullptr, 0, 0, (hipStream_t)stream);
 }
 
 extern "C" int adil_l2ball_project(float* x, int N, int K, float radius, void* stream) {
@@ -471,6 +576,10 @@ extern "C" int adil_dict_rightmul(const float* d, const float* mat, int P, int K
     const size_t lds = ((size_t)K * (K + 1) + (size_t)R * K) * sizeof(float);
     int grid = (P + R - 1) / R;
     if (grid > 1024) grid = 1024;
+    if (lds > 64 * 1024) {                                                   // K >= 127: above the default 64 KB cap
+        hipError_t e = hipFuncSetAttribute((const void*)dict_rightmul_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(dict_rightmul_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, d, mat, P, K, KT, out);
     ADIL_CHECK_LAUNCH();
     return 0;

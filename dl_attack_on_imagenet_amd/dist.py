@@ -14,9 +14,18 @@ import torch
 import torch.distributed as dist
 
 
+def local_device_index(local_rank: int) -> int:
+    """The GPU of this rank: its local rank, one process per GPU.  ADIL_SHARE_GPU=1 (rehearsals on a box with fewer
+    GPUs than ranks, together with ADIL_DIST_BACKEND=gloo — RCCL refuses two ranks on one device) wraps around."""
+    if os.environ.get("ADIL_SHARE_GPU") == "1":
+        return local_rank % max(1, torch.cuda.device_count())
+    return local_rank
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, world_size, local_rank) from torchrun's env; initialises the default process group when
-    WORLD_SIZE > 1.  backend defaults to 'nccl' (= RCCL on ROCm) when a GPU is present, else 'gloo'."""
+    WORLD_SIZE > 1.  backend: argument, else $ADIL_DIST_BACKEND, else 'nccl' (= RCCL on ROCm) when a GPU is
+    present, else 'gloo'."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -24,9 +33,9 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("ADIL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_device_index(local_rank))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -42,6 +51,28 @@ def shard_batch(index: List[int], rank: int, world: int) -> List[int]:
     """This rank's slice of one GLOBAL batch (contiguous rows, as §8e of SURVEY.md)."""
     lo, hi = shard_bounds(len(index), rank, world)
     return list(index[lo:hi])
+
+
+def owned_rows(index, lo: int, hi: int) -> List[int]:
+    """The members of one GLOBAL batch whose images (and code rows) this rank owns, in batch order."""
+    return [int(i) for i in index if lo <= int(i) < hi]
+
+
+def global_epoch_batches(n: int, batch_size: int, world: int, seed: int, epoch: int) -> List[List[int]]:
+    """The GLOBAL batches of one epoch, computed identically on every rank (seeded, no communication).
+
+    Every rank shuffles its own contiguous shard and global batch s is the union of the ranks' s-th chunks of
+    batch_size // world rows, so a global batch is balanced across ranks by construction and all ranks take the SAME
+    number of steps, ceil(largest shard / chunk): a rank whose shard is exhausted contributes an empty chunk and
+    still joins that step's all-reduce (no collective can ever pair with a different one)."""
+    chunk = max(1, batch_size // world)
+    perms = []
+    for r in range(world):
+        lo, hi = shard_bounds(n, r, world)
+        g = torch.Generator().manual_seed(1_000_003 * (seed + 1) + 7919 * epoch + r)
+        perms.append((lo + torch.randperm(hi - lo, generator=g)).tolist())
+    steps = max((len(p) + chunk - 1) // chunk for p in perms)
+    return [[i for p in perms for i in p[s * chunk:(s + 1) * chunk]] for s in range(steps)]
 
 
 class DictGradReducer:
@@ -67,3 +98,13 @@ class DictGradReducer:
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         dist.broadcast(t, src=src, group=self.group)
         return t
+
+    def gather_rows(self, rows: torch.Tensor, counts: List[int]) -> torch.Tensor:
+        """Concatenate the ranks' row blocks (counts[r] rows on rank r, any sizes): blocks are padded to the largest
+        count for the all-gather (RCCL needs equal shapes) and trimmed afterwards.  Used once, when saving V."""
+        width = max(counts)
+        pad = torch.zeros((width,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        pad[:rows.shape[0]] = rows
+        parts = [torch.empty_like(pad) for _ in counts]
+        dist.all_gather(parts, pad, group=self.group)
+        return torch.cat([p[:c] for p, c in zip(parts, counts)])

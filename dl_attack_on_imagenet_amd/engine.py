@@ -91,13 +91,12 @@ class DictionaryLearner:
         self.reducer = reducer
 
     # -- pieces ------------------------------------------------------------- #
-    def _set_pos(self, index: Tensor) -> None:
-        self.pos.fill_(-1)
-        self.pos[index] = torch.arange(index.numel(), dtype=torch.int32, device=index.device)
-
     def forward_backward(self, model, x: Tensor, index: Tensor, labels: Tensor, want_d: bool, want_v: bool):
         b = x.shape[0]
-        vp = ops.pack_codes(self.v, index, b)
+        if b == 0:
+            return self._empty_batch(x, want_d)
+        # the gather of the batch's code rows also records their batch slots in `pos` (consumed + reset by update_v)
+        vp = ops.pack_codes(self.v, index, b, pos=self.pos if want_v else None)
         xt = ops.synth(_flat_images(x), self.d, vp, b)                                  # K1
         out, ls, g = input_gradient(model, xt, labels, self.loss, self.coeff, self.kappa, "sum")
         fooled = (out.argmax(dim=-1) != labels).sum()                                    # adil.py:177
@@ -107,22 +106,35 @@ class DictionaryLearner:
             self.reducer.all_reduce_(gd)                                                 # the ONE collective per step
         return ls, fooled, gd, gvb
 
+    def _empty_batch(self, x: Tensor, want_d: bool):
+        """This rank owns no image of the current global batch (ragged shards): it contributes a zero grad_d and still
+        joins the step's all-reduce, so every rank issues the same collectives in the same order."""
+        zero = torch.zeros((), dtype=torch.float32, device=self.d.device)
+        gd = None
+        if want_d:
+            gd = self.grad_d.zero_()
+            if self.reducer is not None:
+                self.reducer.all_reduce_(gd)
+        return zero, zero.to(torch.int64), gd, None
+
     def update_d(self, gd: Tensor) -> None:
         ops.adamw_clamp_(self.d, gd, self.m_d, self.s_d, self.sched_d.next(), -1.0, 1.0)   # K4: step + update_d
 
-    def update_v(self, gvb: Tensor, index: Tensor) -> None:
-        self._set_pos(index)
-        ops.adamw_l1ball_(self.v, gvb, self.pos, self.m_v, self.s_v, self.sched_v.next(), self.eps)  # K5
+    def update_v(self, gvb: Optional[Tensor]) -> None:
+        if self.v.shape[0] == 0:
+            return
+        ops.adamw_l1ball_(self.v, gvb, self.pos, self.m_v, self.s_v, self.sched_v.next(), self.eps,   # K5
+                          reset_pos=True)
 
     # -- reference loops ---------------------------------------------------- #
     def step(self, model, x: Tensor, index: Tensor, labels: Optional[Tensor] = None):
         """learn_dictionary_a hot-loop body (adil.py:168-191). Returns (loss, #fooled) as 0-d device tensors."""
         index = index.to(device=self.v.device, dtype=torch.int64)
-        if labels is None:
+        if labels is None and x.shape[0]:
             labels = predict(model, x)                                                   # adil.py:172
         ls, fooled, gd, gvb = self.forward_backward(model, x, index, labels, True, True)
         self.update_d(gd)
-        self.update_v(gvb, index)
+        self.update_v(gvb)
         return ls, fooled
 
     def step_codes(self, model, x: Tensor, index: Tensor, labels: Optional[Tensor] = None):
@@ -131,7 +143,7 @@ class DictionaryLearner:
         if labels is None:
             labels = predict(model, x)
         ls, fooled, _, gvb = self.forward_backward(model, x, index, labels, False, True)
-        self.update_v(gvb, index)
+        self.update_v(gvb)
         return ls, fooled
 
     def step_dictionary(self, model, x: Tensor, index: Tensor, labels: Optional[Tensor] = None):
@@ -147,13 +159,22 @@ class DictionaryLearner:
 # --------------------------------------------------------------------------- #
 def solve_codes_adamw(model, images: Tensor, d: Tensor, eps: float, loss: str = "ce", targeted: bool = False,
                       kappa: float = 50.0, norm: str = "linf", mode: str = "train", max_iter: int = 100,
-                      labels: Optional[Tensor] = None, return_codes: bool = False):
+                      labels: Optional[Tensor] = None, return_codes: bool = False, mean_over: Optional[int] = None):
     """forward_supervised_AdamW (adil.py:569-623): per-image codes with D fixed.
-    mode 'train' -> fooled count (0-d tensor); otherwise clamp(images + D proj(v), 0, 1)."""
+    mode 'train' -> fooled count (0-d tensor); otherwise clamp(images + D proj(v), 0, 1).
+    mean_over: size of the GLOBAL batch when `images` is one rank's shard of it — the reference's mean-reduced CE
+    (adil.py:578) then divides by that size, so a sharded validation solves the same problem as an unsharded one."""
     images = _flat_images(images)
     b = images.shape[0]
     p, k = ops.dict_shape(d)
     coeff = 1.0 if targeted else -1.0
+    ce_reduction = "mean"
+    if mean_over is not None and mean_over != b:
+        coeff, ce_reduction = coeff / float(mean_over), "sum"
+    if b == 0:
+        if mode == "train":
+            return torch.zeros((), dtype=torch.int64, device=images.device)
+        return images.clone()
     v = torch.zeros(b, k, dtype=torch.float32, device=images.device)
     m, s = torch.zeros_like(v), torch.zeros_like(v)
     sched = ops.AdamWSchedule(1e-2)
@@ -165,7 +186,7 @@ def solve_codes_adamw(model, images: Tensor, d: Tensor, eps: float, loss: str = 
         iters += 1
         vp = ops.pack_codes(v, None, b)
         xt = ops.synth(images, d, vp, b)
-        _, _, g = input_gradient(model, xt, labels, loss, coeff, kappa, "mean")
+        _, _, g = input_gradient(model, xt, labels, loss, coeff, kappa, ce_reduction)
         _, gvb = ops.grad(g, d, None, b, want_d=False, want_v=True)
         delta.zero_()
         ops.adamw_l1ball_(v, gvb, None, m, s, sched.next(), eps, max_abs_delta=delta)      # adil.py:609-610
@@ -194,9 +215,51 @@ class PseudoInverse:
     def __init__(self, d: Tensor):
         self.d = ops._dev(d, "d", torch.float32)
         self.gram = ops.gram(d)
-        # K x K inverse on the host LAPACK path, as the reference's CPU `dtd.inverse()` (adil.py:524); 4*K*K bytes
-        self.gram_inv = self.gram.cpu().inverse().to(d.device).contiguous()
+        self.gram_inv = ops.spd_inverse(self.gram)         # `dtd.inverse()` (adil.py:524) on the device, fp64 inside
         self.d_pinv_t = ops.dict_rightmul(d, self.gram_inv)
+
+
+class DDragueSolver:
+    """State of forward_supervised_DDrague (adil.py:508-567) on one batch: z (B,C,H,W) fp32 with its AdamW(1e-2)
+    moments; the perturbation is D D_dagger z; z is clamped to +-eps (the perturbation itself is not — quirk Q6).
+    `iterate()` is the loop body (adil.py:539-559), `result()` the output (adil.py:563-567)."""
+
+    def __init__(self, model, images: Tensor, d: Tensor, eps: float, loss: str = "ce", targeted: bool = False,
+                 kappa: float = 50.0, pinv: Optional[PseudoInverse] = None, labels: Optional[Tensor] = None):
+        self.model, self.images, self.d = model, _flat_images(images), d
+        self.b = self.images.shape[0]
+        self.eps, self.loss, self.kappa = float(eps), loss, float(kappa)
+        self.coeff = 1.0 if targeted else -1.0
+        self.dpt = (pinv if pinv is not None else PseudoInverse(d)).d_pinv_t
+        self.z = torch.zeros_like(self.images, dtype=torch.float32)
+        self.m, self.s = torch.zeros_like(self.z), torch.zeros_like(self.z)
+        self.sched = ops.AdamWSchedule(1e-2)
+        self.labels = predict(model, self.images) if labels is None else labels        # adil.py:539 (constant)
+        self.delta = torch.zeros(1, dtype=torch.float32, device=self.images.device)
+        self.iters = 0
+
+    def codes(self) -> Tensor:
+        _, vcode = ops.grad(self.z, self.dpt, None, self.b, want_d=False, want_v=True)  # v = z D_dagger^T (K6)
+        return vcode
+
+    def iterate(self) -> Tensor:
+        """One iteration; returns max|dz| as a 1-element device tensor (the stop test of adil.py:559 reads it)."""
+        b = self.b
+        self.iters += 1
+        vp = ops.pack_codes(self.codes(), None, b)                                       # adil.py:542
+        xt = ops.synth(self.images, self.d, vp, b)                                       # adil.py:543-544
+        _, _, g = input_gradient(self.model, xt, self.labels, self.loss, self.coeff, self.kappa, "mean")
+        _, gv = ops.grad(g, self.d, None, b, want_d=False, want_v=True)                  # dL/dv = g D
+        self.delta.zero_()
+        # dL/dz = (dL/dv) D_dagger is formed inside the kernel and consumed by AdamW(z) + clamp: never materialised (K8)
+        ops.zstep_(self.z, self.m, self.s, self.dpt, ops.pack_codes(gv, None, b), b, self.sched.next(), -self.eps,
+                   self.eps, max_abs_delta=self.delta)
+        return self.delta
+
+    def result(self) -> Tuple[Tensor, Tensor]:
+        vcode = self.codes()
+        adv = ops.synth(self.images, self.d, ops.pack_codes(vcode, None, self.b), self.b, pixel_clamp=True)   # :563-567
+        return adv, vcode
 
 
 def solve_ddrague(model, images: Tensor, d: Tensor, eps: float, steps_inference: int = 30, loss: str = "ce",
@@ -204,38 +267,13 @@ def solve_ddrague(model, images: Tensor, d: Tensor, eps: float, steps_inference:
                   labels: Optional[Tensor] = None, return_trace: bool = False):
     """forward_supervised_DDrague (adil.py:508-567): optimise z (B,C,H,W) with AdamW(1e-2), the perturbation
     being D D_dagger z; z is clamped to +-eps (the perturbation itself is not — quirk Q6)."""
-    images = _flat_images(images)
-    b = images.shape[0]
-    coeff = 1.0 if targeted else -1.0
-    pinv = pinv if pinv is not None else PseudoInverse(d)
-    dpt = pinv.d_pinv_t
-    z = torch.zeros_like(images, dtype=torch.float32)
-    m, s = torch.zeros_like(z), torch.zeros_like(z)
-    sched = ops.AdamWSchedule(1e-2)
-    if labels is None:
-        labels = predict(model, images)                                                  # adil.py:539 (constant)
-    delta = torch.zeros(1, dtype=torch.float32, device=images.device)
-    iters = 0
-
-    def codes_of(zz):
-        _, vcode = ops.grad(zz, dpt, None, b, want_d=False, want_v=True)                 # v = z D_dagger^T (K6)
-        return vcode
-
+    solver = DDragueSolver(model, images, d, eps, loss, targeted, kappa, pinv, labels)
     for _ in range(int(steps_inference)):
-        iters += 1
-        vp = ops.pack_codes(codes_of(z), None, b)                                        # adil.py:542
-        xt = ops.synth(images, d, vp, b)                                                 # adil.py:543-544
-        _, _, g = input_gradient(model, xt, labels, loss, coeff, kappa, "mean")
-        _, gv = ops.grad(g, d, None, b, want_d=False, want_v=True)                       # dL/dv = g D
-        delta.zero_()
-        # dL/dz = (dL/dv) D_dagger is formed inside the kernel and consumed by AdamW(z) + clamp: never materialised (K8)
-        ops.zstep_(z, m, s, dpt, ops.pack_codes(gv, None, b), b, sched.next(), -eps, eps, max_abs_delta=delta)
-        if float(delta) < 1e-6:                                                          # adil.py:559
+        if float(solver.iterate()) < 1e-6:                                               # adil.py:559
             break
-    vcode = codes_of(z)
-    adv = ops.synth(images, d, ops.pack_codes(vcode, None, b), b, pixel_clamp=True)      # adil.py:563-567
+    adv, vcode = solver.result()
     if return_trace:
-        return adv, dict(z=z, v=vcode, iters=iters, labels=labels)
+        return adv, dict(z=solver.z, v=vcode, iters=solver.iters, labels=solver.labels)
     return adv
 
 

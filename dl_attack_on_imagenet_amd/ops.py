@@ -52,7 +52,10 @@ def _stream() -> c_void_p:
 
 
 def _workspace(device: torch.device, nbytes: int) -> Tensor:
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    """Scratch slab of the reductions (grad / gram / atom norms): one per (device, stream), because kernels of two
+    streams may run concurrently and the caching allocator only orders a buffer's reuse on its allocation stream."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.type, idx, torch.cuda.current_stream(idx).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -93,8 +96,9 @@ class AdamWSchedule:
 
 
 # --------------------------------------------------------------------------- #
-def pack_codes(v: Tensor, index: Optional[Tensor], batch: Optional[int] = None) -> Tensor:
-    """vp [roundup(B,32)][roundup(K,16)] = zero-padded v[index] (adil.py:25 `self.v[index, :]`)."""
+def pack_codes(v: Tensor, index: Optional[Tensor], batch: Optional[int] = None, pos: Optional[Tensor] = None) -> Tensor:
+    """vp [roundup(B,32)][roundup(K,16)] = zero-padded v[index] (adil.py:25 `self.v[index, :]`).
+    pos (int32, one entry per row of v, all -1): receives pos[index[b]] = b for adamw_l1ball_(..., reset_pos=True)."""
     lib = _lib.load()
     _dev(v, "v", torch.float32)
     k = v.shape[1]
@@ -103,9 +107,39 @@ def pack_codes(v: Tensor, index: Optional[Tensor], batch: Optional[int] = None) 
         b = index.numel()
     else:
         b = v.shape[0] if batch is None else batch
+    if pos is not None:
+        _dev(pos, "pos", torch.int32)
+        if pos.numel() != v.shape[0]:
+            raise ValueError("pos must have one entry per row of v")
     vp = torch.empty(_round_up(b, 32), _round_up(k, 16), dtype=torch.float32, device=v.device)
-    _lib.check(lib.adil_pack_codes(_ptr(v), _ptr(index), b, k, _ptr(vp), _stream()), "adil_pack_codes")
+    _lib.check(lib.adil_pack_codes(_ptr(v), _ptr(index), b, k, _ptr(vp), _ptr(pos), _stream()), "adil_pack_codes")
     return vp
+
+
+def gather_images(src: Tensor, index: Optional[Tensor], out: Optional[Tensor] = None,
+                  dtype: Optional[torch.dtype] = None) -> Tensor:
+    """out[b] = src[index[b]] converted to `dtype` — one batch of a dataset resident in HBM (src: (R,C,H,W)).
+    index None: rows 0..B-1 of src into `out` (a pure cast, used when the dataset is uploaded)."""
+    lib = _lib.load()
+    _dev(src, "src")
+    if index is not None:
+        index = _dev(index.to(device=src.device, dtype=torch.int64), "index")
+        b = index.numel()
+    else:
+        b = src.shape[0] if out is None else out.shape[0]
+    if out is None:
+        out = torch.empty((b,) + tuple(src.shape[1:]), dtype=src.dtype if dtype is None else dtype, device=src.device)
+    _dev(out, "out")
+    p = src[0].numel() if src.shape[0] else 0
+    if b == 0:
+        return out
+    if out.numel() != b * p or p % 8:
+        raise ValueError("gather_images: out must be (B,) + src.shape[1:] and the image size a multiple of 8")
+    if index is None and b > src.shape[0]:
+        raise ValueError("gather_images: more output rows than source rows")
+    _lib.check(lib.adil_gather_images(_ptr(src), stream_dtype_code(src.dtype), _ptr(index), _ptr(out),
+                                      stream_dtype_code(out.dtype), b, p, _stream()), "adil_gather_images")
+    return out
 
 
 def synth(x: Optional[Tensor], d: Tensor, vp: Tensor, batch: int, *, out: Optional[Tensor] = None,
@@ -194,27 +228,32 @@ def zstep_(z: Tensor, m: Tensor, s: Tensor, dpinv_t: Tensor, gvp: Tensor, batch:
                               h.step_size, h.bc2_sqrt, float(lo), float(hi), _ptr(max_abs_delta), _stream()), "adil_zstep")
 
 
-def adamw_l1ball_(v: Tensor, grad_vb: Tensor, pos: Optional[Tensor], m: Tensor, s: Tensor, h: AdamWScalars,
-                  radius: float, max_abs_delta: Optional[Tensor] = None) -> None:
+def adamw_l1ball_(v: Tensor, grad_vb: Optional[Tensor], pos: Optional[Tensor], m: Tensor, s: Tensor, h: AdamWScalars,
+                  radius: float, max_abs_delta: Optional[Tensor] = None, reset_pos: bool = False) -> None:
     """In-place AdamW on ALL rows of v (zero gradient outside the batch) + l1-ball projection
-    (adil.py:186-187; radius < 0 skips the projection)."""
+    (adil.py:186-187; radius < 0 skips the projection).  pos is the batch-slot table written by pack_codes; with
+    reset_pos the kernel hands it back all -1.  grad_vb None = no row of this v is in the batch (pos all -1)."""
     lib = _lib.load()
-    for name, t in (("v", v), ("m", m), ("s", s), ("grad_vb", grad_vb)):
+    for name, t in (("v", v), ("m", m), ("s", s)):
         _dev(t, name, torch.float32)
     n, k = v.shape
+    if grad_vb is not None:
+        _dev(grad_vb, "grad_vb", torch.float32)
+        if grad_vb.shape[1] != k:
+            raise ValueError("adamw_l1ball_: shape mismatch")
     if pos is not None:
         _dev(pos, "pos", torch.int32)
         if pos.numel() != n:
             raise ValueError("pos must have one entry per row of v")
-    elif grad_vb.shape[0] != n:
+    elif grad_vb is None or grad_vb.shape[0] != n:
         raise ValueError("without pos, grad_vb must have one row per row of v")
-    if grad_vb.shape[1] != k or m.shape != v.shape or s.shape != v.shape:
+    if m.shape != v.shape or s.shape != v.shape:
         raise ValueError("adamw_l1ball_: shape mismatch")
     if max_abs_delta is not None:
         _dev(max_abs_delta, "max_abs_delta", torch.float32)
-    _lib.check(lib.adil_adamw_l1ball(_ptr(v), _ptr(grad_vb), _ptr(pos), _ptr(m), _ptr(s), n, k, h.decay, h.b1, h.b2,
-                                     h.eps, h.step_size, h.bc2_sqrt, float(radius), _ptr(max_abs_delta), _stream()),
-               "adil_adamw_l1ball")
+    _lib.check(lib.adil_adamw_l1ball(_ptr(v), _ptr(grad_vb), _ptr(pos), int(bool(reset_pos)), _ptr(m), _ptr(s), n, k,
+                                     h.decay, h.b1, h.b2, h.eps, h.step_size, h.bc2_sqrt, float(radius),
+                                     _ptr(max_abs_delta), _stream()), "adil_adamw_l1ball")
 
 
 def l1ball_project_(x: Tensor, radius: float) -> Tensor:
@@ -283,6 +322,18 @@ def gram(d: Tensor) -> Tensor:
     return out
 
 
+def spd_inverse(a: Tensor) -> Tensor:
+    """Inverse of the K x K Gram matrix on the device (`dtd.inverse()`, adil.py:524): no host round trip."""
+    lib = _lib.load()
+    _dev(a, "a", torch.float32)
+    k = a.shape[0]
+    if a.shape != (k, k):
+        raise ValueError("spd_inverse: square matrix expected")
+    out = torch.empty_like(a)
+    _lib.check(lib.adil_spd_inverse(_ptr(a), k, _ptr(out), _stream()), "adil_spd_inverse")
+    return out
+
+
 def dict_rightmul(d: Tensor, mat: Tensor) -> Tensor:
     """D M^T as a (C,H,W,K) tensor; with M = (DtD)^-1 this is D_dagger^T (adil.py:525)."""
     lib = _lib.load()
@@ -333,7 +384,9 @@ class AffineActFunction(torch.autograd.Function):
         _dev(scale, "scale", torch.float32)
         _dev(shift, "shift", torch.float32)
         inner = _channel_inner(x)
-        if res is not None and (res.shape != x.shape or _channel_inner(res) != inner or res.dtype != x.dtype):
+        if res is not None and res.shape != x.shape:
+            raise ValueError(f"affine_act: residual shape {tuple(res.shape)} != activation shape {tuple(x.shape)}")
+        if res is not None and (_channel_inner_or_none(res) != inner or res.dtype != x.dtype):
             res = res.to(x.dtype).contiguous(memory_format=torch.channels_last if inner == 1 else torch.contiguous_format)
         y = torch.empty_like(x)
         if x.numel() > 0:                                             # empty batches pass through like plain torch modules

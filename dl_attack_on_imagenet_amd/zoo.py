@@ -1,7 +1,8 @@
 """Frozen ImageNet classifiers for the ADiL CLIs and benchmarks, in plain torch.
 
 torchvision is not available in this image and pretrained weights are a network fetch, so the architectures the
-reference takes from torchvision (demo_dL_attack.py:41-53: resnet18, densenet121, mobilenet_v2, vgg11, ...) and
+reference takes from torchvision (demo_dL_attack.py:41-53: resnet18, densenet121, googlenet, inception_v3, mobilenet_v2,
+vgg11 — all six) and
 the ones BASELINE.json names (ResNet-50, DenseNet-121, ViT-B/16) are defined here with torchvision-compatible
 parameter names: a torchvision state_dict on local disk loads with `weights=path`.  Without weights the networks
 are randomly initialised from a seed (synthetic throughput / plumbing runs).
@@ -286,6 +287,218 @@ class VGG11(nn.Module):
         return self.classifier(torch.flatten(self.avgpool(self.features(x)), 1))
 
 
+# ----------------------------------------------------------------------------- GoogLeNet / Inception-v3
+class _ConvBN(nn.Module):
+    """conv (no bias) -> BatchNorm(eps 1e-3) -> ReLU; parameter names `conv.*` / `bn.*` as in torchvision's BasicConv2d."""
+
+    def __init__(self, inp, out, **kw):
+        super().__init__()
+        self.conv = nn.Conv2d(inp, out, bias=False, **kw)
+        self.bn = nn.BatchNorm2d(out, eps=0.001)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.conv(x)), inplace=True)
+
+
+def _seeded_init(net):
+    """Variance-preserving random weights for the no-checkpoint runs (eval-mode BatchNorm with fresh statistics is the
+    identity, so the published truncated-normal(0.1) initialisation would overflow bf16 after a few blocks)."""
+    for m in net.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+
+def _to_half_range(x):
+    """The input re-scaling torchvision applies to its pretrained GoogLeNet / Inception-v3 (`transform_input=True`): the
+    networks were trained on (x - 0.5) / 0.5, so ImageNet-normalised input is mapped back channel by channel."""
+    c0 = x[:, 0:1] * (0.229 / 0.5) + (0.485 - 0.5) / 0.5
+    c1 = x[:, 1:2] * (0.224 / 0.5) + (0.456 - 0.5) / 0.5
+    c2 = x[:, 2:3] * (0.225 / 0.5) + (0.406 - 0.5) / 0.5
+    return torch.cat((c0, c1, c2), 1)
+
+
+class _GoogLeNetBlock(nn.Module):
+    def __init__(self, inp, c1, c3r, c3, c5r, c5, pool):
+        super().__init__()
+        self.branch1 = _ConvBN(inp, c1, kernel_size=1)
+        self.branch2 = nn.Sequential(_ConvBN(inp, c3r, kernel_size=1), _ConvBN(c3r, c3, kernel_size=3, padding=1))
+        # a 3x3 convolution here too: torchvision's published weights were trained with it in place of the paper's 5x5
+        self.branch3 = nn.Sequential(_ConvBN(inp, c5r, kernel_size=1), _ConvBN(c5r, c5, kernel_size=3, padding=1))
+        self.branch4 = nn.Sequential(nn.MaxPool2d(3, stride=1, padding=1, ceil_mode=True), _ConvBN(inp, pool, kernel_size=1))
+
+    def forward(self, x):
+        return torch.cat([self.branch1(x), self.branch2(x), self.branch3(x), self.branch4(x)], 1)
+
+
+class GoogLeNet(nn.Module):
+    """GoogLeNet (Szegedy et al. 2015) with torchvision's module names; inference graph only (the two auxiliary heads
+    exist for training and are dropped by torchvision's pretrained constructor as well)."""
+
+    def __init__(self, num_classes=1000, transform_input=True):
+        super().__init__()
+        self.transform_input = transform_input
+        self.conv1 = _ConvBN(3, 64, kernel_size=7, stride=2, padding=3)
+        self.maxpool1 = nn.MaxPool2d(3, stride=2, ceil_mode=True)
+        self.conv2 = _ConvBN(64, 64, kernel_size=1)
+        self.conv3 = _ConvBN(64, 192, kernel_size=3, padding=1)
+        self.maxpool2 = nn.MaxPool2d(3, stride=2, ceil_mode=True)
+        self.inception3a = _GoogLeNetBlock(192, 64, 96, 128, 16, 32, 32)
+        self.inception3b = _GoogLeNetBlock(256, 128, 128, 192, 32, 96, 64)
+        self.maxpool3 = nn.MaxPool2d(3, stride=2, ceil_mode=True)
+        self.inception4a = _GoogLeNetBlock(480, 192, 96, 208, 16, 48, 64)
+        self.inception4b = _GoogLeNetBlock(512, 160, 112, 224, 24, 64, 64)
+        self.inception4c = _GoogLeNetBlock(512, 128, 128, 256, 24, 64, 64)
+        self.inception4d = _GoogLeNetBlock(512, 112, 144, 288, 32, 64, 64)
+        self.inception4e = _GoogLeNetBlock(528, 256, 160, 320, 32, 128, 128)
+        self.maxpool4 = nn.MaxPool2d(2, stride=2, ceil_mode=True)
+        self.inception5a = _GoogLeNetBlock(832, 256, 160, 320, 32, 128, 128)
+        self.inception5b = _GoogLeNetBlock(832, 384, 192, 384, 48, 128, 128)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.dropout = nn.Dropout(0.2)
+        self.fc = nn.Linear(1024, num_classes)
+        _seeded_init(self)
+
+    def forward(self, x):
+        if self.transform_input:
+            x = _to_half_range(x)
+        x = self.maxpool2(self.conv3(self.conv2(self.maxpool1(self.conv1(x)))))
+        x = self.maxpool3(self.inception3b(self.inception3a(x)))
+        x = self.inception4e(self.inception4d(self.inception4c(self.inception4b(self.inception4a(x)))))
+        x = self.inception5b(self.inception5a(self.maxpool4(x)))
+        return self.fc(self.dropout(torch.flatten(self.avgpool(x), 1)))
+
+
+class _InceptionA(nn.Module):
+    def __init__(self, inp, pool_features):
+        super().__init__()
+        self.branch1x1 = _ConvBN(inp, 64, kernel_size=1)
+        self.branch5x5_1 = _ConvBN(inp, 48, kernel_size=1)
+        self.branch5x5_2 = _ConvBN(48, 64, kernel_size=5, padding=2)
+        self.branch3x3dbl_1 = _ConvBN(inp, 64, kernel_size=1)
+        self.branch3x3dbl_2 = _ConvBN(64, 96, kernel_size=3, padding=1)
+        self.branch3x3dbl_3 = _ConvBN(96, 96, kernel_size=3, padding=1)
+        self.branch_pool = _ConvBN(inp, pool_features, kernel_size=1)
+
+    def forward(self, x):
+        return torch.cat([self.branch1x1(x), self.branch5x5_2(self.branch5x5_1(x)),
+                          self.branch3x3dbl_3(self.branch3x3dbl_2(self.branch3x3dbl_1(x))),
+                          self.branch_pool(F.avg_pool2d(x, 3, stride=1, padding=1))], 1)
+
+
+class _InceptionB(nn.Module):
+    def __init__(self, inp):
+        super().__init__()
+        self.branch3x3 = _ConvBN(inp, 384, kernel_size=3, stride=2)
+        self.branch3x3dbl_1 = _ConvBN(inp, 64, kernel_size=1)
+        self.branch3x3dbl_2 = _ConvBN(64, 96, kernel_size=3, padding=1)
+        self.branch3x3dbl_3 = _ConvBN(96, 96, kernel_size=3, stride=2)
+
+    def forward(self, x):
+        return torch.cat([self.branch3x3(x), self.branch3x3dbl_3(self.branch3x3dbl_2(self.branch3x3dbl_1(x))),
+                          F.max_pool2d(x, 3, stride=2)], 1)
+
+
+class _InceptionC(nn.Module):
+    def __init__(self, inp, c7):
+        super().__init__()
+        self.branch1x1 = _ConvBN(inp, 192, kernel_size=1)
+        self.branch7x7_1 = _ConvBN(inp, c7, kernel_size=1)
+        self.branch7x7_2 = _ConvBN(c7, c7, kernel_size=(1, 7), padding=(0, 3))
+        self.branch7x7_3 = _ConvBN(c7, 192, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7dbl_1 = _ConvBN(inp, c7, kernel_size=1)
+        self.branch7x7dbl_2 = _ConvBN(c7, c7, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7dbl_3 = _ConvBN(c7, c7, kernel_size=(1, 7), padding=(0, 3))
+        self.branch7x7dbl_4 = _ConvBN(c7, c7, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7dbl_5 = _ConvBN(c7, 192, kernel_size=(1, 7), padding=(0, 3))
+        self.branch_pool = _ConvBN(inp, 192, kernel_size=1)
+
+    def forward(self, x):
+        b7 = self.branch7x7_3(self.branch7x7_2(self.branch7x7_1(x)))
+        bd = self.branch7x7dbl_5(self.branch7x7dbl_4(self.branch7x7dbl_3(self.branch7x7dbl_2(self.branch7x7dbl_1(x)))))
+        return torch.cat([self.branch1x1(x), b7, bd, self.branch_pool(F.avg_pool2d(x, 3, stride=1, padding=1))], 1)
+
+
+class _InceptionD(nn.Module):
+    def __init__(self, inp):
+        super().__init__()
+        self.branch3x3_1 = _ConvBN(inp, 192, kernel_size=1)
+        self.branch3x3_2 = _ConvBN(192, 320, kernel_size=3, stride=2)
+        self.branch7x7x3_1 = _ConvBN(inp, 192, kernel_size=1)
+        self.branch7x7x3_2 = _ConvBN(192, 192, kernel_size=(1, 7), padding=(0, 3))
+        self.branch7x7x3_3 = _ConvBN(192, 192, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7x3_4 = _ConvBN(192, 192, kernel_size=3, stride=2)
+
+    def forward(self, x):
+        b7 = self.branch7x7x3_4(self.branch7x7x3_3(self.branch7x7x3_2(self.branch7x7x3_1(x))))
+        return torch.cat([self.branch3x3_2(self.branch3x3_1(x)), b7, F.max_pool2d(x, 3, stride=2)], 1)
+
+
+class _InceptionE(nn.Module):
+    def __init__(self, inp):
+        super().__init__()
+        self.branch1x1 = _ConvBN(inp, 320, kernel_size=1)
+        self.branch3x3_1 = _ConvBN(inp, 384, kernel_size=1)
+        self.branch3x3_2a = _ConvBN(384, 384, kernel_size=(1, 3), padding=(0, 1))
+        self.branch3x3_2b = _ConvBN(384, 384, kernel_size=(3, 1), padding=(1, 0))
+        self.branch3x3dbl_1 = _ConvBN(inp, 448, kernel_size=1)
+        self.branch3x3dbl_2 = _ConvBN(448, 384, kernel_size=3, padding=1)
+        self.branch3x3dbl_3a = _ConvBN(384, 384, kernel_size=(1, 3), padding=(0, 1))
+        self.branch3x3dbl_3b = _ConvBN(384, 384, kernel_size=(3, 1), padding=(1, 0))
+        self.branch_pool = _ConvBN(inp, 192, kernel_size=1)
+
+    def forward(self, x):
+        b3 = self.branch3x3_1(x)
+        b3 = torch.cat([self.branch3x3_2a(b3), self.branch3x3_2b(b3)], 1)
+        bd = self.branch3x3dbl_2(self.branch3x3dbl_1(x))
+        bd = torch.cat([self.branch3x3dbl_3a(bd), self.branch3x3dbl_3b(bd)], 1)
+        return torch.cat([self.branch1x1(x), b3, bd, self.branch_pool(F.avg_pool2d(x, 3, stride=1, padding=1))], 1)
+
+
+class InceptionV3(nn.Module):
+    """Inception-v3 (Szegedy et al. 2016) with torchvision's module names; inference graph only (no AuxLogits).  Fully
+    convolutional up to the adaptive pool, so the reference's 224x224 crops run (DS_ImageNet.py:14-18) as well as 299."""
+
+    def __init__(self, num_classes=1000, transform_input=True):
+        super().__init__()
+        self.transform_input = transform_input
+        self.Conv2d_1a_3x3 = _ConvBN(3, 32, kernel_size=3, stride=2)
+        self.Conv2d_2a_3x3 = _ConvBN(32, 32, kernel_size=3)
+        self.Conv2d_2b_3x3 = _ConvBN(32, 64, kernel_size=3, padding=1)
+        self.maxpool1 = nn.MaxPool2d(kernel_size=3, stride=2)
+        self.Conv2d_3b_1x1 = _ConvBN(64, 80, kernel_size=1)
+        self.Conv2d_4a_3x3 = _ConvBN(80, 192, kernel_size=3)
+        self.maxpool2 = nn.MaxPool2d(kernel_size=3, stride=2)
+        self.Mixed_5b = _InceptionA(192, 32)
+        self.Mixed_5c = _InceptionA(256, 64)
+        self.Mixed_5d = _InceptionA(288, 64)
+        self.Mixed_6a = _InceptionB(288)
+        self.Mixed_6b = _InceptionC(768, 128)
+        self.Mixed_6c = _InceptionC(768, 160)
+        self.Mixed_6d = _InceptionC(768, 160)
+        self.Mixed_6e = _InceptionC(768, 192)
+        self.Mixed_7a = _InceptionD(768)
+        self.Mixed_7b = _InceptionE(1280)
+        self.Mixed_7c = _InceptionE(2048)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.dropout = nn.Dropout(0.5)
+        self.fc = nn.Linear(2048, num_classes)
+        _seeded_init(self)
+
+    def forward(self, x):
+        if self.transform_input:
+            x = _to_half_range(x)
+        x = self.maxpool1(self.Conv2d_2b_3x3(self.Conv2d_2a_3x3(self.Conv2d_1a_3x3(x))))
+        x = self.maxpool2(self.Conv2d_4a_3x3(self.Conv2d_3b_1x1(x)))
+        x = self.Mixed_5d(self.Mixed_5c(self.Mixed_5b(x)))
+        x = self.Mixed_6e(self.Mixed_6d(self.Mixed_6c(self.Mixed_6b(self.Mixed_6a(x)))))
+        x = self.Mixed_7c(self.Mixed_7b(self.Mixed_7a(x)))
+        return self.fc(self.dropout(torch.flatten(self.avgpool(x), 1)))
+
+
+# auxiliary training heads present in torchvision checkpoints; the inference graphs above do not have them
+_TRAINING_ONLY_PREFIXES = ('aux1.', 'aux2.', 'AuxLogits.')
+
+
 # ----------------------------------------------------------------------------- registry
 _BUILDERS = {
     'resnet18': lambda nc: ResNet(BasicBlock, [2, 2, 2, 2], nc),
@@ -294,19 +507,18 @@ _BUILDERS = {
     'vit_b_16': lambda nc: VisionTransformer(num_classes=nc),
     'mobilenet_v2': lambda nc: MobileNetV2(nc),
     'vgg11': lambda nc: VGG11(nc),
+    'googlenet': lambda nc: GoogLeNet(nc),
+    'inception_v3': lambda nc: InceptionV3(nc),
 }
 # names accepted by the reference CLIs (demo_dL_attack.py:41-53) and the BASELINE.json config names
 ALIASES = {'resnet': 'resnet18', 'densenet': 'densenet121', 'mobilenet': 'mobilenet_v2', 'vgg': 'vgg11',
-           'vit': 'vit_b_16', 'vit-b/16': 'vit_b_16', 'resnet-50': 'resnet50', 'densenet-121': 'densenet121'}
-UNSUPPORTED = {'googlenet': 'GoogLeNet', 'inception': 'Inception-v3'}
+           'vit': 'vit_b_16', 'vit-b/16': 'vit_b_16', 'resnet-50': 'resnet50', 'densenet-121': 'densenet121',
+           'inception': 'inception_v3'}
 
 
 def canonical_name(name: str) -> str:
     key = name.lower()
     key = ALIASES.get(key, key)
-    if key in UNSUPPORTED:
-        raise NotImplementedError(f"{UNSUPPORTED[key]} is not defined in this build (no torchvision here); "
-                                  f"available: {sorted(_BUILDERS)}")
     if key not in _BUILDERS:
         raise ValueError(f"unknown model {name!r}; available: {sorted(_BUILDERS) + sorted(ALIASES)}")
     return key
@@ -390,7 +602,20 @@ def _bn_affine(bn: nn.BatchNorm2d):
     return scale.contiguous(), shift.contiguous()
 
 
-class _ConvAffine(nn.Module):
+class _Fp32Tables(nn.Module):
+    """The per-channel epilogue tables `scale` / `shift` are derived in fp64 and kept in fp32 whatever dtype the
+    network is cast to: `.to(torch.bfloat16)` would otherwise round them to 8 mantissa bits (and a later `.float()`
+    cannot bring the bits back).  They follow device moves only."""
+
+    def _apply(self, fn, recurse=True):
+        keep = {n: getattr(self, n) for n in ('scale', 'shift')}
+        super()._apply(fn, recurse)
+        for n, t in keep.items():
+            setattr(self, n, t.to(device=fn(t).device))
+        return self
+
+
+class _ConvAffine(_Fp32Tables):
     """conv (weights untouched) followed by the fused eval-BatchNorm [+ residual] [+ ReLU] epilogue kernel."""
 
     def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool):
@@ -494,7 +719,7 @@ class _FusedResBlock(nn.Module):
         return self.c2(out, res=idt)
 
 
-class _FusedStem(nn.Module):
+class _FusedStem(_Fp32Tables):
     """Normalize -> conv1 7x7/2 -> bn1(eval) -> ReLU -> maxpool as the hand-written stem kernels (`ops.resnet_stem`):
     consumes the attack's (B,3,H,W) fp32/bf16 tensor directly and returns bf16 channels_last activations; its
     backward produces dLoss/dx in the layout `adil_grad` reads.  bf16 networks on the GPU only."""
@@ -561,7 +786,8 @@ def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights:
         torch.manual_seed(seed)
         net = _BUILDERS[key](num_classes)
     if weights is not None:
-        net.load_state_dict(torch.load(weights, map_location='cpu'))
+        state = torch.load(weights, map_location='cpu')
+        net.load_state_dict({k: v for k, v in state.items() if not k.startswith(_TRAINING_ONLY_PREFIXES)})
     net.eval()
     mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
     stem_fused = False
@@ -579,9 +805,6 @@ def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights:
     model = model.to(device=device, dtype=dtype)
     if channels_last:
         model = model.to(memory_format=torch.channels_last)
-    for m in model.modules():                                # epilogue tables stay fp32 whatever the activation dtype
-        if isinstance(m, (_ConvAffine, _FusedStem)):
-            m.scale, m.shift = m.scale.float(), m.shift.float()
     if pad_input_channels and not stem_fused:
         pad_first_conv_(net, pad_input_channels)
     return model

@@ -38,7 +38,8 @@ extern "C" {
 #define ADIL_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported K) */
 #define ADIL_EWORKSPACE (-2) /* workspace too small */
 
-/* ABI version of this header (currently 2: v2 added the frozen-classifier entry points); bumped on any signature change. */
+/* ABI version of this header; bumped on any signature change.  2: frozen-classifier entry points.  3: batch-slot table
+ * written by adil_pack_codes and consumed + reset by adil_adamw_l1ball, adil_gather_images, adil_spd_inverse. */
 int adil_abi_version(void);
 
 /* Largest K (atoms) the kernels support. */
@@ -49,8 +50,16 @@ size_t adil_grad_workspace_bytes(int B, int P, int K);
 
 /* Gather + pad the batch's code rows:  vp[b][k] = v[index[b]][k] (0 for k>=K, b>=B).
  * Replaces the advanced-indexing `self.v[index, :]` of Attack_dict_model.forward
- * (adil.py:25).  index may be NULL (rows 0..B-1, as adil.py:600 `range(n_img)`). */
-int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, void* stream);
+ * (adil.py:25).  index may be NULL (rows 0..B-1, as adil.py:600 `range(n_img)`).
+ * pos (optional, one int32 per row of v, all -1 on entry): pos[index[b]] = b — the batch-slot table that
+ * adil_adamw_l1ball consumes; it is what autograd's scatter of the batch gradient into a dense (N,K) grad does. */
+int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, int32_t* pos, void* stream);
+
+/* Batched image gather, the data step in front of the path (the DataLoader's per-item fetch + torch.stack + .to(device)
+ * of adil.py:130-133,168-170 on a dataset that is resident in HBM): dst[b][:] = convert(src[index[b]][:]).
+ * src is R x P (src_dtype), dst is B x P (dst_dtype), index may be NULL (rows 0..B-1: a pure cast).  P % 8 == 0. */
+int adil_gather_images(const void* src, int src_dtype, const int64_t* index, void* dst, int dst_dtype, int B, int P,
+                       void* stream);
 
 /* Perturbation synthesis, fused with the add and the optional clamps:
  *     delta = vp D^T ;  delta = clamp(delta, -delta_clamp, +delta_clamp)   if delta_clamp >= 0
@@ -95,10 +104,13 @@ int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, const float* 
  * The gradient is non-zero only for the rows of the current batch: pos[n] = b if row n is
  * batch slot b (gradient row grad_vb[b]), -1 otherwise (zero gradient; the row still
  * moves through momentum and weight decay — reference quirk Q3).  pos may be NULL
- * (row n <-> grad_vb[n], N == B).  radius < 0 skips the projection.
+ * (row n <-> grad_vb[n], N == B).  With reset_pos every consumed slot is written back to -1, so the table
+ * filled by adil_pack_codes is all -1 again for the next batch (no fill / scatter launches in between).
+ * grad_vb may be NULL when pos is given and holds no slot (a rank with an empty shard of the batch).
+ * radius < 0 skips the projection.
  * Replaces optimise.step() + update_v (adil.py:186-187 with :29-31 and utils.py:21-41),
  * and the same pair in forward_supervised_AdamW (adil.py:609-610, :614). */
-int adil_adamw_l1ball(float* v, const float* grad_vb, const int32_t* pos, float* m, float* s, int N, int K,
+int adil_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, int reset_pos, float* m, float* s, int N, int K,
                       float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt, float radius,
                       float* max_abs_delta, void* stream);
 
@@ -123,6 +135,10 @@ int adil_atom_scale(float* d, int P, int K, const float* norms, int sphere, void
 /* Gram matrix  gram (K x K) = D^T D   (adil.py:523). ws: adil_atom_workspace_bytes(P, K*K)… see .hip */
 size_t adil_gram_workspace_bytes(int P, int K);
 int adil_gram(const float* d, int P, int K, float* gram, void* ws, size_t ws_bytes, void* stream);
+
+/* out (K x K) = a^-1 for a symmetric positive definite K x K matrix (the Gram matrix; `dtd.inverse()`, adil.py:524).
+ * One workgroup, fp64 Gauss-Jordan in LDS; no host round trip. */
+int adil_spd_inverse(const float* a, int K, float* out, void* stream);
 
 /* out (P x K) = D M^T  with M (K x K):  D_dagger^T = D (DtD^-1)^T   (adil.py:525, stored P x K). */
 int adil_dict_rightmul(const float* d, const float* mat, int P, int K, float* out, void* stream);

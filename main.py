@@ -43,7 +43,7 @@ def main(args):
         return
     torch.cuda.set_device(0)
     device = torch.device('cuda', 0)
-    model_name = zoo.canonical_name(args.model)
+    model_name = args.model.lower()          # names the dictionary file, as upstream (main.py:40, adil.py:89-91)
     model = zoo.build_classifier(model_name, weights=args.weights, device=device)
     if args.synthetic:
         im = torch.rand(3, args.image_size, args.image_size, generator=torch.Generator().manual_seed(0))

@@ -664,6 +664,24 @@ def performance(attack_fn: Callable[[Tensor, Tensor], Tensor], model, batches: S
     return dict(fooling_rate=fooling / num, rmse=rmse / num, mse=mse / num, num_samples=num)
 
 
+def transfer_performance(attack_fn: Callable[[Tensor, Tensor], Tensor], targets, batches: Sequence[Tuple[Tensor, Tensor]],
+                         num_samples: int):
+    """get_transfer_performance_aux (performance.py:205-232): the adversary is computed ONCE per batch (against
+    the source model, inside attack_fn), then every target model is scored on it; unlike performance() there is
+    no correctly-classified filter and the sums are divided by the dataset size.  `targets`: name -> model."""
+    perf = {name: {"fooling_rate": 0.0, "rmse": 0.0, "mse": 0.0} for name in targets}
+    for x, y in batches:
+        adversary = attack_fn(x, y)
+        if isinstance(adversary, tuple):
+            adversary = adversary[0]
+        adversary = adversary.detach()
+        for name, model in targets.items():
+            perf[name]["fooling_rate"] += compute_fooling_rate(model, adversary, x) / num_samples   # performance.py:227
+            perf[name]["rmse"] += compute_rmse(adversary, x) / num_samples                           # performance.py:229
+            perf[name]["mse"] += compute_mse(adversary, x) / num_samples                             # performance.py:230
+    return perf
+
+
 def sadil_updated(model, images: Tensor, labels: Tensor, d0: Tensor, targeted: bool = True, nepochs: int = 3,
                   batchsize: int = 1, lambda_coding: float = 1.0, l2_fool: float = 1.0, stepsize: float = 1.0,
                   dict_set: str = "l2ball"):

@@ -524,11 +524,42 @@ def g14_uappgd():
     save("g14_uappgd", images=images, val=val, labels=labels, batch_size=bs, steps=steps, beta=9.0, **state_to_npz_dict(net), **out)
 
 
+def g15_transfer():
+    """Transfer evaluation (performance.py:183-232): ONE dictionary, adversaries from the reference's own ADIL
+    (DDrague inference against the source net), scored on the source and two other toy targets."""
+    g = torch.Generator().manual_seed(115)
+    n, k, eps, steps = 14, 6, 0.12, 8
+    images = torch.rand(n, 3, 16, 16, generator=g)
+    d = -1 + 2 * torch.rand(3, 16, 16, k, generator=g)
+    src = make_tinynet(1115)
+    targets = {"src": src, "t1": make_tinynet(2115), "t2": make_tinynet(3115)}
+    labels = src(images).argmax(-1)
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(images, labels), batch_size=5, shuffle=False)
+    with scratch_cwd():
+        torch.save([d, torch.zeros(1), [], [], torch.tensor(0.)], "trained_dicts/ImageNet_g15.bin")
+        atk = quiet(A.ADIL, src, eps=eps, n_atoms=k, attack="supervised", model_name="g15", loss="logits",
+                    steps_inference=steps, kappa=50)
+        perf = quiet(PERF.get_transfer_performance, {"adil": [atk], "none": []}, targets, loader)
+    assert set(perf) == {"adil", "none"} and all(np.isnan(v["mse"]) for v in perf["none"].values())
+    operf = O.transfer_performance(lambda x, y: O.forward_supervised_ddrague(src, x, d, eps, steps, "logits", False, 50.0),
+                                   targets, [(images[i:i + 5], labels[i:i + 5]) for i in range(0, n, 5)], n)
+    out = {}
+    for name in targets:
+        for key in ("fooling_rate", "rmse", "mse"):
+            e = close(operf[name][key], float(perf["adil"][name][key]), 1e-6 if key != "mse" else 1e-4, f"{name}.{key}")
+            out[f"{name}_{key}"] = float(perf["adil"][name][key])
+        print(f"  g15[{name}] fooling {out[name + '_fooling_rate']:.4f} rmse {out[name + '_rmse']:.5f} mse {out[name + '_mse']:.4f}")
+    nets = {}
+    for name, net in targets.items():
+        nets.update(state_to_npz_dict(net, prefix=f"{name}."))
+    save("g15_transfer", images=images, labels=labels, d=d, eps=eps, steps=steps, kappa=50.0, batch_size=5, **nets, **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (g1_l1ball, g2_constraints, g3_softshrink, g4_synth_grad, g5_floss, g6_adamw_steps, g7_learn_a,
                g8_learn_b, g9_ddrague, g10_adamw_inference, g11_unsupervised, g12_ista_and_metrics, g13_sadil_updated,
-               g14_uappgd):
+               g14_uappgd, g15_transfer):
         if only and fn.__name__.split("_")[0] not in only:
             continue
         print(fn.__name__)

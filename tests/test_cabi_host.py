@@ -127,11 +127,13 @@ def test_zoo_names_and_shapes():
     from dl_attack_on_imagenet_amd import zoo
     assert zoo.canonical_name("resnet") == "resnet18" and zoo.canonical_name("DenseNet") == "densenet121"
     assert zoo.canonical_name("mobilenet") == "mobilenet_v2" and zoo.canonical_name("vgg") == "vgg11"
-    with pytest.raises(NotImplementedError):
-        zoo.canonical_name("googlenet")
+    assert zoo.canonical_name("googlenet") == "googlenet" and zoo.canonical_name("inception") == "inception_v3"
     with pytest.raises(ValueError):
         zoo.canonical_name("alexnet")
-    for name, nparam in (("resnet18", 11689512), ("resnet50", 25557032), ("densenet121", 7978856)):
+    # all six names of the reference CLI (demo_dL_attack.py:41-53) + the BASELINE.json ones; parameter counts are the
+    # published ones of the torchvision definitions (googlenet / inception_v3 without their training-only aux heads)
+    for name, nparam in (("resnet18", 11689512), ("resnet50", 25557032), ("densenet121", 7978856),
+                         ("googlenet", 6624904), ("inception", 23834568), ("mobilenet", 3504872), ("vgg", 132863336)):
         m = zoo.build_classifier(name, seed=1)
         assert sum(p.numel() for p in m[1].parameters()) == nparam          # torchvision-compatible definitions
         assert not any(p.requires_grad for p in m.parameters()) and not m.training
@@ -140,6 +142,85 @@ def test_zoo_names_and_shapes():
     a = zoo.build_classifier("resnet18", seed=3)[1].fc.weight
     b = zoo.build_classifier("resnet18", seed=3)[1].fc.weight
     assert torch.equal(a, b)
+
+
+def test_weights_round_trip_with_torchvision_key_names(tmp_path):
+    """`--weights`: a state_dict with torchvision's key names on local disk loads into the zoo definitions (the keys
+    listed are the well-known ones of torchvision's checkpoints), training-only aux heads in a checkpoint are ignored,
+    and the loaded network computes the checkpoint's function, not the seed's."""
+    from dl_attack_on_imagenet_amd import zoo
+    expected = {
+        "resnet18": ["conv1.weight", "bn1.running_var", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight",
+                     "layer4.1.bn2.num_batches_tracked", "fc.bias"],
+        "resnet50": ["layer1.0.conv3.weight", "layer1.0.downsample.1.running_mean", "layer4.2.bn3.weight", "fc.weight"],
+        "densenet121": ["features.conv0.weight", "features.denseblock1.denselayer1.norm1.weight",
+                        "features.denseblock4.denselayer16.conv2.weight", "features.transition3.conv.weight",
+                        "features.norm5.bias", "classifier.weight"],
+        "vit_b_16": ["class_token", "conv_proj.weight", "encoder.pos_embedding",
+                     "encoder.layers.encoder_layer_0.self_attention.in_proj_weight",
+                     "encoder.layers.encoder_layer_11.mlp.3.bias", "encoder.ln.weight", "heads.head.weight"],
+        "mobilenet_v2": ["features.0.0.weight", "features.1.conv.0.0.weight", "features.18.1.running_var", "classifier.1.weight"],
+        "vgg11": ["features.0.weight", "features.18.bias", "classifier.0.weight", "classifier.6.bias"],
+        "googlenet": ["conv1.conv.weight", "conv1.bn.running_mean", "inception3a.branch2.1.conv.weight",
+                      "inception5b.branch4.1.bn.weight", "fc.weight"],
+        "inception_v3": ["Conv2d_1a_3x3.conv.weight", "Mixed_5b.branch5x5_2.conv.weight", "Mixed_6e.branch7x7dbl_5.bn.bias",
+                         "Mixed_7c.branch3x3dbl_3b.conv.weight", "fc.bias"],
+    }
+    for name, keys in expected.items():
+        sd = zoo._BUILDERS[name](1000).state_dict()
+        missing = [k for k in keys if k not in sd]
+        assert not missing, (name, missing)
+    for name in ("resnet18", "googlenet"):
+        src = zoo.build_classifier(name, seed=11)
+        state = dict(src[1].state_dict())
+        if name == "googlenet":                                   # torchvision's googlenet checkpoint carries the aux heads
+            state["aux1.conv.conv.weight"] = torch.zeros(128, 512, 1, 1)
+            state["aux2.fc2.bias"] = torch.zeros(1000)
+        path = tmp_path / f"{name}.pth"
+        torch.save(state, path)
+        loaded = zoo.build_classifier(name, seed=99, weights=str(path))
+        other = zoo.build_classifier(name, seed=99)
+        x = torch.rand(2, 3, 64, 64)
+        assert torch.equal(loaded(x), src(x)) and not torch.equal(other(x), src(x))
+    with pytest.raises(RuntimeError):                            # a checkpoint of another architecture fails loudly
+        zoo.build_classifier("resnet50", weights=str(tmp_path / "resnet18.pth"))
+
+
+def test_epilogue_tables_stay_fp32_under_dtype_casts():
+    """FusedResNet's BatchNorm scale/shift tables are derived in fp64 and must survive `.to(bfloat16)` unrounded."""
+    from dl_attack_on_imagenet_amd import zoo
+    net = zoo.ResNet(zoo.Bottleneck, [1, 1, 1, 1])
+    g = torch.Generator().manual_seed(0)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g))
+            m.weight.data.copy_(0.5 + torch.rand(m.weight.shape, generator=g))
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=g))
+    want = zoo._bn_affine(net.bn1)
+    fused = zoo.FusedResNet(net, normalize=([0.485, 0.456, 0.406], [0.229, 0.224, 0.225]))
+    fused = fused.to(dtype=torch.bfloat16).to(memory_format=torch.channels_last)
+    stem = [m for m in fused.modules() if isinstance(m, zoo._FusedStem)][0]
+    assert stem.scale.dtype == torch.float32 and torch.equal(stem.scale, want[0]) and torch.equal(stem.shift, want[1])
+    tables = [m for m in fused.modules() if isinstance(m, zoo._Fp32Tables)]
+    assert len(tables) > 10 and all(m.scale.dtype == m.shift.dtype == torch.float32 for m in tables)
+    assert all(p.dtype == torch.bfloat16 for p in fused.parameters())
+
+
+def test_shuffled_batches_follow_the_reference_dataloader():
+    """loader.shuffled_batches consumes the global torch RNG exactly like `DataLoader(shuffle=True)` (adil.py:130-133):
+    same seed -> same index batches, epoch after epoch, with a second (validation) loader interleaved."""
+    from dl_attack_on_imagenet_amd.loader import shuffled_batches
+    torch.manual_seed(3)
+    tr = torch.utils.data.DataLoader(torch.arange(37), batch_size=5, shuffle=True)
+    va = torch.utils.data.DataLoader(torch.arange(11), batch_size=5, shuffle=True)
+    want = []
+    for _ in range(3):
+        want.append(([b.tolist() for b in tr], [b.tolist() for b in va]))
+    torch.manual_seed(3)
+    got = [(shuffled_batches(37, 5), shuffled_batches(11, 5)) for _ in range(3)]
+    assert got == want
+    assert shuffled_batches(7, 3, shuffle=False) == [[0, 1, 2], [3, 4, 5], [6]]
 
 
 def test_dataset_protocol_and_split():

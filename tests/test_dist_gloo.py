@@ -1,9 +1,13 @@
-"""CPU, world_size 2, gloo: the data-parallel path of the learner (dl_attack_on_imagenet_amd.dist) — rendezvous from
-torchrun-style env, contiguous sharding, ONE all-reduce(SUM) of grad_d per step, scalar bookkeeping.
+"""CPU, world_size 2, gloo: the data-parallel learner of the PRODUCT — `ADIL.learn_dictionary_distributed` itself
+(dl_attack_on_imagenet_amd/attacks/adil.py): rendezvous from torchrun-style env, image / code-row ownership, global
+batches filtered by ownership (ragged shards, a rank that owns nothing of a batch), ONE all-reduce(SUM) of grad_d per
+step through the product's DictGradReducer, the equal step count on every rank, scalar bookkeeping, sharded
+validation, the padded gather of V and the saved file.
 
-The HIP kernels cannot run here, so each rank evaluates its shard's contributions with the ORACLE (test-side stand-in
-for the kernels) and the product's reducer combines them; the result must equal the single-process oracle learner
-at the GLOBAL batch (the parity target of SURVEY.md §8e): D bit-for-bit identical on both ranks, V rows owned per rank."""
+The HIP kernels cannot run here, so the three places the learner touches them are swapped for test-side stand-ins
+built on the ORACLE (the (D, V) update, the validation solver, the resident image store); everything else is the
+shipped code.  The result must equal the single-process oracle learner at the GLOBAL batches (the parity target of
+SURVEY.md §8e): D bit-for-bit identical on both ranks, V rows owned per rank."""
 import os
 import socket
 import sys
@@ -15,6 +19,11 @@ import torch.multiprocessing as mp
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
+N_IMG, N_VAL, K, EPS, STEPS, BATCH = 17, 7, 4, 0.5, 3, 6          # 17 and 7 do not divide by 2: ragged shards
+# explicit global batches (second scenario): batch 0 is owned by rank 0 only, batch 1 by rank 1 only
+EXPLICIT = [[[0, 1, 2, 3], [9, 10, 11, 12, 13], [4, 16, 8]], [[5, 6, 14, 15, 7], [3, 2, 1], [16, 9, 0]]]
+EXPLICIT_VAL = [[[0, 1, 2], [3, 4, 5, 6]], [[6, 0, 3], [1, 2, 4, 5]]]
+
 
 def _free_port():
     with socket.socket() as s:
@@ -22,85 +31,162 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _problem():
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
+    from oracle import adil_oracle as O
+    from tinynet import make_tinynet
+    g = torch.Generator().manual_seed(0)
+    images = torch.rand(N_IMG, 3, 16, 16, generator=g)
+    val = torch.rand(N_VAL, 3, 16, 16, generator=g)
+    d0 = -1 + 2 * torch.rand(3, 16, 16, K, generator=g)
+    v0raw = torch.rand(N_IMG, K, generator=g)
+    return O, make_tinynet(11), images, val, d0, v0raw
+
+
+class _Indexed(torch.utils.data.Dataset):
+    def __init__(self, images):
+        self.images, self.indexed = images, False
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, i):
+        return (i, self.images[i], 0) if self.indexed else (self.images[i], 0)
+
+
+def _install_oracle_backend(O):
+    """Swap the HIP-touching pieces of the learner for oracle-backed stand-ins (test side only)."""
+    from dl_attack_on_imagenet_amd import engine, ops
+    from dl_attack_on_imagenet_amd.attacks import adil as A
+
+    class OracleLearner:
+        """Interface of engine.DictionaryLearner; maths by the oracle, collective by the product's reducer."""
+
+        def __init__(self, d, v, eps, step_size=0.01, loss="ce", targeted=False, kappa=50.0, lr_d=None, lr_v=None,
+                     reducer=None):
+            self.d, self.v, self.eps, self.loss, self.kappa = d, v, eps, loss, kappa
+            self.coeff = 1.0 if targeted else -1.0
+            self.opt_d, self.opt_v = O.AdamWState(d, step_size), O.AdamWState(v, step_size)
+            self.reducer = reducer
+            self.collectives = 0
+
+        def step(self, model, x, index, labels=None):
+            if x.shape[0]:
+                with torch.no_grad():
+                    label = model(x).argmax(-1)
+                out, ls, gin = O._input_grad(model, O.synth(x, self.d, self.v[index]), label, self.loss, self.coeff,
+                                             self.kappa, "sum")
+                gd, gvr = O.grad_dv(gin, self.d, self.v[index])
+                fooled = (out.argmax(-1) != label).sum()
+            else:
+                gd, gvr, ls, fooled = torch.zeros_like(self.d), None, torch.zeros(()), torch.zeros((), dtype=torch.int64)
+            self.reducer.all_reduce_(gd)                          # <- the product's single collective per step
+            self.collectives += 1
+            gv = torch.zeros_like(self.v)
+            if gvr is not None:
+                gv[index] = gvr
+            self.opt_d.step(self.d, gd)
+            if self.v.shape[0]:
+                self.opt_v.step(self.v, gv)
+                self.v.copy_(O.project_onto_l1_ball(self.v, self.eps))
+            self.d.clamp_(-1, 1)
+            return ls, fooled
+
+    class HostImages:
+        """Interface of loader.ResidentImages on host tensors."""
+
+        def __init__(self, dataset, device, dtype=torch.float32, rows=None, chunk=256):
+            dataset.indexed = False
+            self.rows = list(range(len(dataset))) if rows is None else list(rows)
+            self.images = torch.stack([dataset[r][0] for r in self.rows]) if self.rows else torch.zeros(0, 3, 16, 16)
+
+        def __len__(self):
+            return len(self.rows)
+
+        def gather(self, index, dtype=None):
+            return self.images[torch.as_tensor(list(index), dtype=torch.int64)]
+
+        def batches(self, order):
+            for idx in order:
+                index = torch.as_tensor([int(i) for i in idx], dtype=torch.int64)
+                yield index, self.images[index]
+
+    def solve_codes(model, images, d, eps, loss="ce", targeted=False, kappa=50.0, norm="linf", mode="train",
+                    max_iter=100, labels=None, return_codes=False, mean_over=None):
+        assert loss == "logits", "the stand-in ignores mean_over, which only matters for the mean-reduced CE"
+        if images.shape[0] == 0:
+            return torch.zeros((), dtype=torch.int64)
+        return torch.as_tensor(O.forward_supervised_adamw(model, images, d, eps, loss=loss, targeted=targeted, kappa=kappa,
+                                                          norm=norm, mode=mode))
+
+    A.ADIL._learner_cls = OracleLearner
+    A.ResidentImages = HostImages
+    engine.solve_codes_adamw = solve_codes
+    ops.l1ball_project_ = lambda x, r: x.copy_(O.project_onto_l1_ball(x, r))
+
+
+def _worker(rank, world, port, out_dir):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     torch.set_num_threads(1)
+    O, net, images, val, d0, v0raw = _problem()
     from dl_attack_on_imagenet_amd import dist as adist
-    from oracle import adil_oracle as O
-    from tinynet import make_tinynet
+    from dl_attack_on_imagenet_amd.attacks.adil import ADIL
 
-    r, w, lr = adist.init_from_env(backend="gloo")
+    r, w, _ = adist.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
-    reducer = adist.DictGradReducer()
-
-    # identical problem on every rank (seeded), sharded by ownership
-    g = torch.Generator().manual_seed(0)
-    n, k, eps, steps, gb = 16, 4, 0.5, 3, 8                     # gb = GLOBAL batch
-    images = torch.rand(n, 3, 16, 16, generator=g)
-    d = -1 + 2 * torch.rand(3, 16, 16, k, generator=g)
-    v_all = O.project_onto_l1_ball(torch.rand(n, k, generator=g), eps)
-    net = make_tinynet(11)
-    lo, hi = adist.shard_bounds(n, rank, world)
-    v = v_all[lo:hi].clone()                                     # this rank's code rows
-    opt_d, opt_v = O.AdamWState(d, 0.01), O.AdamWState(v, 0.01)
-    # global batches = union of per-rank batches of gb/world owned images (deterministic order)
-    local_batches = [[(s * (gb // world) + j) % (hi - lo) for j in range(gb // world)] for s in range(steps)]
-    tot_loss, tot_fooled = 0.0, 0
-    for idx in local_batches:
-        index = torch.tensor(idx)
-        x = images[lo:hi][index]
-        with torch.no_grad():
-            label = net(x).argmax(-1)
-        xt = O.synth(x, d, v[index])
-        out, ls, gin = O._input_grad(net, xt, label, "logits", -1.0, 50.0, "sum")
-        gd, gvr = O.grad_dv(gin, d, v[index])
-        reducer.all_reduce_(gd)                                  # <- the product's single collective per step
-        gv = torch.zeros_like(v)
-        gv[index] = gvr
-        opt_d.step(d, gd)
-        opt_v.step(v, gv)
-        v.copy_(O.project_onto_l1_ball(v, eps))
-        d.clamp_(-1, 1)
-        tot_loss += float(ls)
-        tot_fooled += int((out.argmax(-1) != label).sum())
-    sums = reducer.sum_scalars(torch.tensor(tot_loss), torch.tensor(tot_fooled))
-    d0 = d.clone()
-    reducer.broadcast_(d0, 0)
-    assert torch.equal(d0, d), "replicated dictionary diverged across ranks"
-    torch.save(dict(d=d, v=v, lo=lo, hi=hi, sums=sums, local_batches=local_batches), os.path.join(out_dir, f"r{rank}.pt"))
+    _install_oracle_backend(O)
+    for tag, explicit, vexplicit in (("seeded", None, None), ("explicit", EXPLICIT, EXPLICIT_VAL)):
+        steps = STEPS if explicit is None else len(explicit)
+        atk = ADIL(net, eps=EPS, steps=steps, n_atoms=K, batch_size=BATCH, data_train=_Indexed(images),
+                   data_val=_Indexed(val), model_name=f"dist_{tag}", step_size=0.01, is_distributed=True, loss="logits",
+                   kappa=50.0, init_d=d0, init_v=v0raw, epoch_batches=explicit, val_batches=vexplicit,
+                   dict_dir=os.path.join(out_dir, "dicts"), shuffle_seed=5)
+        assert os.path.exists(atk.model_file)                      # rank 0 saved before the final barrier
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_learning_matches_single_process_global_batch(tmp_path):
+@pytest.mark.timeout(600)
+def test_product_distributed_learner_matches_single_process_global_batch(tmp_path):
     world, port = 2, _free_port()
     mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
-    sys.path.insert(0, HERE)
-    from oracle import adil_oracle as O
-    from tinynet import make_tinynet
-    res = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
-    assert torch.equal(res[0]["d"], res[1]["d"])
+    O, net, images, val, d0, v0raw = _problem()
+    from dl_attack_on_imagenet_amd import dist as adist
+    v0 = O.project_onto_l1_ball(v0raw, EPS)
+    for tag, explicit, vexplicit in (("seeded", None, None), ("explicit", EXPLICIT, EXPLICIT_VAL)):
+        d, v, loss_all, fooling_rate_all, val_fool = torch.load(tmp_path / "dicts" / f"ImageNet_dist_{tag}.bin")
+        if explicit is None:
+            explicit = [adist.global_epoch_batches(N_IMG, BATCH, world, 5, e) for e in range(STEPS)]
+            vexplicit = [adist.global_epoch_batches(N_VAL, BATCH, world, 6, e) for e in range(STEPS)]
+            sizes = [len(b) for b in explicit[0]]
+            assert sorted(i for b in explicit[0] for i in b) == list(range(N_IMG))      # one epoch = every image once
+            assert sizes == [6, 6, 5]                              # 9 + 8 images in chunks of 3: equal step count, ragged tail
+        # single-process reference at the same GLOBAL batches
+        ref = O.learn_dictionary_a(net, images, d0, v0, explicit, EPS, 0.01, "logits", False, 50.0, val_images=val,
+                                   val_batches=vexplicit)
+        assert d.shape == d0.shape and v.shape == (N_IMG, K)
+        assert float((ref["d"] - d).abs().max()) < 2e-6, tag                       # fp32 summation order only
+        assert float((ref["v"] - v).abs().max()) < 2e-6, tag
+        assert max(abs(a - b) for a, b in zip(ref["loss_all"], loss_all)) < 1e-4 * max(1.0, max(map(abs, ref["loss_all"])))
+        assert list(fooling_rate_all) == list(ref["fooling_rate_all"])
+        assert abs(float(val_fool) - ref["val_fool"]) < 1e-6
 
-    # single-process reference at the global batch = union of the shards' batches
-    g = torch.Generator().manual_seed(0)
-    n, k, eps = 16, 4, 0.5
-    images = torch.rand(n, 3, 16, 16, generator=g)
-    d0 = -1 + 2 * torch.rand(3, 16, 16, k, generator=g)
-    v0 = O.project_onto_l1_ball(torch.rand(n, k, generator=g), eps)
-    net = make_tinynet(11)
-    steps = len(res[0]["local_batches"])
-    epochs = [[[res[r]["lo"] + i for r in range(world) for i in res[r]["local_batches"][s]]] for s in range(steps)]
-    ref = O.learn_dictionary_a(net, images, d0, v0, epochs, eps, 0.01, "logits", False, 50.0)
-    assert float((ref["d"] - res[0]["d"]).abs().max()) < 2e-6                     # fp32 summation order only
-    v = torch.cat([res[r]["v"] for r in range(world)])
-    assert float((ref["v"] - v).abs().max()) < 2e-6
-    total_loss = sum(l * n for l in ref["loss_all"])
-    assert abs(res[0]["sums"][0] - total_loss) < 1e-3 * max(1.0, abs(total_loss))
-    assert res[0]["sums"][1] == sum(f * n for f in ref["fooling_rate_all"])
+
+def test_global_epoch_batches_equal_steps_and_ownership():
+    sys.path.insert(0, ROOT)
+    from dl_attack_on_imagenet_amd import dist as adist
+    # the advisor's example: 1001 images, 2 ranks, batch 100 -> both ranks must take the same number of steps
+    batches = adist.global_epoch_batches(1001, 100, 2, 0, 0)
+    bounds = [adist.shard_bounds(1001, r, 2) for r in range(2)]
+    per_rank = [[adist.owned_rows(b, *bounds[r]) for b in batches] for r in range(2)]
+    assert len(per_rank[0]) == len(per_rank[1]) == len(batches) == 11
+    assert sorted(i for b in batches for i in b) == list(range(1001))
+    assert [len(x) for x in per_rank[1]][-1] == 0                  # rank 1 (500 images) is empty on the last step ...
+    assert [len(x) for x in per_rank[0]][-1] == 1                  # ... where rank 0 (501) still has one image
+    assert adist.global_epoch_batches(1001, 100, 2, 0, 0) == batches                    # deterministic
+    assert adist.global_epoch_batches(1001, 100, 2, 0, 1) != batches                    # reshuffled every epoch
 
 
 def test_init_from_env_single_process(monkeypatch):

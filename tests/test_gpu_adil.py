@@ -233,49 +233,126 @@ def test_end_to_end_round_trip_full_size(tmp_path):
     assert torch.isfinite(adv).all()
 
 
-def test_config1_resnet18_parity():
-    """BASELINE.json configs[0]: resnet18, 32 images of 3x224x224, 10 atoms, 20 inner iterations, fp32 — the
-    reference's own CPU-runnable case.  HIP learner (GPU) vs the CPU oracle on identical seeded inputs.
+def test_transfer_performance_golden(tmp_path):
+    """configs[3] path: performance.get_transfer_performance on the product ADIL (DDrague inference against the source
+    net) against the reference's own numbers (golden G15): fooling rates exact on all three targets."""
+    import performance as perf
+    from attacks import ADIL
+    z = load_golden("g15_transfer")
+    targets = {name: tinynet_from_npz(z, prefix=f"{name}.").to(DEV) for name in ("src", "t1", "t2")}
+    torch.save([t(z["d"]), torch.zeros(1), [], [], torch.tensor(0.)], os.path.join(tmp_path, "ImageNet_g15.bin"))
+    atk = ADIL(targets["src"], eps=float(z["eps"]), n_atoms=z["d"].shape[-1], attack="supervised", model_name="g15",
+               loss="logits", steps_inference=int(z["steps"]), kappa=float(z["kappa"]), dict_dir=str(tmp_path))
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(t(z["images"]), t(z["labels"])),
+                                         batch_size=int(z["batch_size"]), shuffle=False)
+    out = perf.get_transfer_performance({"adil": [atk], "none": []}, targets, loader, device=torch.device(DEV))
+    assert set(out) == {"adil", "none"} and all(np.isnan(v["mse"]) for v in out["none"].values())
+    for name in targets:
+        assert abs(out["adil"][name]["fooling_rate"] - float(z[f"{name}_fooling_rate"])) <= 1e-9, name
+        assert abs(out["adil"][name]["rmse"] - float(z[f"{name}_rmse"])) <= 1e-6
+        assert abs(out["adil"][name]["mse"] - float(z[f"{name}_mse"])) <= 1e-3
 
-    Two levels, because the 20-iteration trajectory of a ReLU network under AdamW is chaotic in the last bits: the SAME
-    oracle code run on CPU and on GPU tensors (only the classifier backend differs: MKL vs MIOpen, dLoss/dx equal to
-    1e-6 relative) ends 0.1 apart in 30 % of the dictionary entries (tools/exp_parity.py).  So (a) every single step
-    from an identical state must agree tightly, (b) the trajectory must agree in what the attack is about: fooling
-    counts and loss."""
-    from dl_attack_on_imagenet_amd import engine, zoo
-    from oracle import adil_oracle as O
-    n, k, T, eps = 32, 10, 20, 8 / 255
-    g = torch.Generator().manual_seed(21)
-    images = torch.rand(n, 3, 224, 224, generator=g)
-    d0 = -1 + 2 * torch.rand(3, 224, 224, k, generator=g)
-    v0 = O.project_onto_l1_ball(torch.rand(n, k, generator=g), eps)
-    cpu_model = zoo.build_classifier("resnet18", seed=5)
-    gpu_model = zoo.build_classifier("resnet18", seed=5, device=DEV)
-    index = torch.arange(n)
-    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
-    od, ov = d0.clone(), v0.clone()
-    sd, sv = O.AdamWState(od, 0.01), O.AdamWState(ov, 0.01)
-    learner = engine.DictionaryLearner(d0.to(DEV), v0.to(DEV), eps, 0.01, "logits", False, 50.0)
-    x_gpu = images.to(DEV)
-    fooled_cpu, fooled_gpu, loss_cpu, loss_gpu = [], [], [], []
-    for it in range(T):
-        ls, fl = O.learn_step_a(cpu_model, images, index, od, ov, sd, sv, eps, "logits", -1.0, 50.0)
-        loss_cpu.append(ls); fooled_cpu.append(fl)
-        ls, fl = learner.step(gpu_model, x_gpu, index.to(DEV))
-        loss_gpu.append(float(ls)); fooled_gpu.append(int(fl))
-        if it == 0:                                               # (a) one step from the identical state
-            dd = (learner.d.cpu() - od).abs()
-            e_v = float((learner.v.cpu() - ov).abs().max())
-            flips = float((dd > 1e-4).float().mean())             # first AdamW step = lr*sign(g): flips where g ~ 0
-            print("config1 step-1: |dD| median %.2e, entries off by > 1e-4: %.2e, |dV| %.2e" % (float(dd.median()), flips, e_v))
-            assert float(dd.median()) <= 1e-6 and flips <= 1e-3 and e_v <= 1e-5
-            assert fooled_cpu == fooled_gpu and abs(loss_cpu[0] - loss_gpu[0]) <= 1e-4 * max(1.0, abs(loss_cpu[0]))
-    print("config1 trajectory: fooled cpu %s gpu %s" % (fooled_cpu, fooled_gpu))
-    # (b) trajectory: fooling counts within one image at every iteration, equal at the end; loss within 2 %
-    assert max(abs(a - b) for a, b in zip(fooled_cpu, fooled_gpu)) <= 1
-    assert fooled_cpu[-1] == fooled_gpu[-1]
-    assert max(abs(a - b) for a, b in zip(loss_cpu, loss_gpu)) <= 2e-2 * max(abs(a) for a in loss_cpu)
-    assert float((learner.v.cpu() - ov).abs().max()) <= 5e-3      # codes stay close (l1 radius 0.031)
+
+def test_warm_start_reads_the_reference_4tuple(tmp_path, monkeypatch):
+    """adil.py:139-143: warm_start loads D from dict_model_ImageNet_version_constrained/ImageNet_{model}_num_atom_{K}
+    _nepoch_{steps}_AdamW_200.bin, a 4-TUPLE whose first element is the dictionary.  A run warm-started from that file
+    equals a run handed the same dictionary through init_d, bit for bit."""
+    from attacks import ADIL
+    from tinynet import make_tinynet
+    monkeypatch.chdir(tmp_path)
+    net = make_tinynet(7).to(DEV)
+    g = torch.Generator().manual_seed(2)
+    images = torch.rand(10, 3, 16, 16, generator=g)
+    d_ws = -1 + 2 * torch.rand(3, 16, 16, 4, generator=g)
+    v0 = torch.rand(10, 4, generator=g)
+    os.makedirs("dict_model_ImageNet_version_constrained")
+    torch.save((d_ws, torch.zeros(10, 4), [0.5], [0.1]),
+               "dict_model_ImageNet_version_constrained/ImageNet_ws_num_atom_4_nepoch_2_AdamW_200.bin")
+    batches = [[[0, 1, 2, 3, 4], [5, 6, 7, 8, 9]]] * 2
+    kw = dict(eps=0.3, steps=2, n_atoms=4, batch_size=5, data_val=None, loss="logits", init_v=v0, epoch_batches=batches)
+    ADIL(net, data_train=IndexedTensorDataset(images), model_name="ws", warm_start=True, dict_dir="warm", **kw)
+    ADIL(net, data_train=IndexedTensorDataset(images), model_name="ws", init_d=d_ws, dict_dir="cold", **kw)
+    a, b = torch.load("warm/ImageNet_ws.bin", map_location="cpu"), torch.load("cold/ImageNet_ws.bin", map_location="cpu")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+    assert not torch.equal(a[0], d_ws)                                  # it did learn from there
+
+
+def test_resident_loader_and_reference_batch_order(tmp_path):
+    """The data step (loader.ResidentImages): every image uploaded once through the pinned double buffer (chunk < N),
+    batches by one gather kernel; and the learner's default batch order is the reference's shuffled-DataLoader order:
+    a seeded run without injected batches equals the run handed the batches a real DataLoader serves for that seed."""
+    from attacks import ADIL
+    from dl_attack_on_imagenet_amd.loader import ResidentImages
+    from tinynet import make_tinynet
+    g = torch.Generator().manual_seed(4)
+    images, val = torch.rand(23, 3, 16, 16, generator=g), torch.rand(9, 3, 16, 16, generator=g)
+    for dt in (torch.float32, torch.bfloat16):
+        res = ResidentImages(IndexedTensorDataset(images), DEV, dt, chunk=5)        # 5 staging rounds, 2 buffers
+        assert torch.equal(res.images.cpu(), images.to(dt))
+        sub = ResidentImages(IndexedTensorDataset(images), DEV, dt, rows=range(7, 19), chunk=4)
+        assert torch.equal(sub.gather([0, 11, 3]).cpu(), images[[7, 18, 10]].to(dt))
+    net = make_tinynet(8).to(DEV)
+    d0, v0 = -1 + 2 * torch.rand(3, 16, 16, 4, generator=g), torch.rand(23, 4, generator=g)
+    kw = dict(eps=0.3, steps=2, n_atoms=4, batch_size=6, loss="logits", init_d=d0, init_v=v0)
+    torch.manual_seed(77)
+    ADIL(net, data_train=IndexedTensorDataset(images), data_val=IndexedTensorDataset(val), model_name="auto",
+         dict_dir=str(tmp_path), **kw)
+    torch.manual_seed(77)                                                # what the reference's two DataLoaders would serve
+    tr = torch.utils.data.DataLoader(torch.arange(23), batch_size=6, shuffle=True)
+    va = torch.utils.data.DataLoader(torch.arange(9), batch_size=6, shuffle=True)
+    eb, vb = [], []
+    for _ in range(2):
+        eb.append([b.tolist() for b in tr])
+        vb.append([b.tolist() for b in va])
+    ADIL(net, data_train=IndexedTensorDataset(images), data_val=IndexedTensorDataset(val), model_name="inj",
+         dict_dir=str(tmp_path), epoch_batches=eb, val_batches=vb, **kw)
+    a, b = torch.load(tmp_path / "ImageNet_auto.bin", map_location="cpu"), torch.load(tmp_path / "ImageNet_inj.bin", map_location="cpu")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and float(a[4]) == float(b[4])
+
+
+def test_single_rank_rccl_reducer_is_bitwise_neutral(tmp_path):
+    """The RCCL path on one rank (process group 'nccl', world 1): a learner whose grad_d goes through
+    DictGradReducer.all_reduce_ equals the learner without reducer bit for bit, and the product's data-parallel
+    learner (learn_dictionary_distributed) equals learn_dictionary_a on the same global batches."""
+    import socket
+    import torch.distributed as tdist
+    from attacks import ADIL
+    from dl_attack_on_imagenet_amd import dist as adist, engine
+    from tinynet import make_tinynet
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ADIL_FORCE_REDUCER="1")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        adist.init_from_env(backend="nccl")
+        net = make_tinynet(9).to(DEV)
+        g = torch.Generator().manual_seed(6)
+        images = torch.rand(12, 3, 32, 32, generator=g)
+        d0, v0 = -1 + 2 * torch.rand(3, 32, 32, 5, generator=g), torch.rand(12, 5, generator=g)
+        va = engine.ops.l1ball_project_(v0.clone().to(DEV), 0.3)
+        la = engine.DictionaryLearner(d0.clone().to(DEV), va.clone(), 0.3, 0.01, "logits")
+        lb = engine.DictionaryLearner(d0.clone().to(DEV), va.clone(), 0.3, 0.01, "logits", reducer=adist.DictGradReducer())
+        idx = torch.arange(12, device=DEV)
+        for _ in range(3):
+            la.step(net, images.to(DEV), idx); lb.step(net, images.to(DEV), idx)
+        assert torch.equal(la.d, lb.d) and torch.equal(la.v, lb.v)
+        batches = [[[0, 5, 7, 2, 9, 11], [1, 3, 4, 6, 8, 10]]] * 2
+        kw = dict(eps=0.3, steps=2, n_atoms=5, batch_size=6, loss="logits", init_d=d0, init_v=v0, epoch_batches=batches,
+                  dict_dir=str(tmp_path))
+        ADIL(net, data_train=IndexedTensorDataset(images), model_name="dp", is_distributed=True, **kw)
+        ADIL(net, data_train=IndexedTensorDataset(images), model_name="sp", **kw)
+        a, b = torch.load(tmp_path / "ImageNet_dp.bin", map_location="cpu"), torch.load(tmp_path / "ImageNet_sp.bin", map_location="cpu")
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[3] == b[3]
+    finally:
+        if tdist.is_initialized():
+            tdist.destroy_process_group()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.parametrize("tag,norm,optim", [("linf_adam", "linf", "adam"), ("l2_sgd", "l2", "sgd")])
@@ -297,3 +374,28 @@ def test_uappgd_baseline_matches_reference_run(tag, norm, optim, tmp_path):
     assert atk.train_fooled == [int(f) for f in z[f"{tag}_train_fooled"]]
     adv = atk(images.to(DEV), labels.to(DEV))                         # forward: clamp(images + attack, 0, 1) from the saved file
     close(adv, (images + t(z[f"{tag}_attack"])).clamp(0, 1), 2e-5)
+
+
+def test_demo_cli_result_dumps(tmp_path, monkeypatch):
+    """demo_dL_attack.py end to end on a seeded synthetic dataset: the dictionary file is named after the CLI's model
+    string as upstream (trained_dicts/ImageNet_resnet.bin, adil.py:89-91) and the two result dumps carry the reference's
+    file names and layout (demo_dL_attack.py:148-156: {'fooling_rate','rmse','mse','time'} -> {sub_name: [values]})."""
+    import demo_dL_attack
+    monkeypatch.chdir(tmp_path)
+    args = demo_dL_attack.build_parser().parse_args(
+        ["-m", "resnet", "-s", "4", "--synthetic", "--synthetic-classes", "3", "--trained-classes", "3", "--image-size", "64",
+         "--n-atoms", "4", "--steps", "2", "--batch-size", "2", "--steps-inference", "3"])
+    torch.random.manual_seed(args.seed)
+    val_perf, test_perf = demo_dL_attack.main(args)
+    d, v, loss_all, fooling_rate_all, val_fool = torch.load("trained_dicts/ImageNet_resnet.bin", map_location="cpu")
+    assert d.shape == (3, 64, 64, 4) and v.shape == (3, 4) and len(loss_all) == 2 and len(fooling_rate_all) == 2
+    out = "dict_model_ImageNet_version_constrained"
+    val_dump = torch.load(os.path.join(out, "model_sampling_adil_inference_rlts_sampling_3_3_4_ce.bin"), weights_only=False)
+    test_dump = torch.load(os.path.join(out, "model_adil_resultat_test_ce.bin"), weights_only=False)
+    for dump, ret in ((val_dump, val_perf), (test_dump, test_perf)):
+        assert set(dump) == {"fooling_rate", "rmse", "mse", "time"}
+        assert list(dump["fooling_rate"]) == ["adil_atoms_4_loss_logits_"]
+        assert len(dump["rmse"]["adil_atoms_4_loss_logits_"]) == 1
+        a = float(dump["fooling_rate"]["adil_atoms_4_loss_logits_"][0])
+        b = float(ret["fooling_rate"]["adil_atoms_4_loss_logits_"][0])
+        assert a == b or (a != a and b != b)          # NaN when the synthetic labels leave nothing "correctly classified"

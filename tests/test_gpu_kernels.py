@@ -298,13 +298,76 @@ def test_adamw_clamp_vs_torch(n, gdtype):
 
 def test_gram_pinv():
     gen = torch.Generator().manual_seed(5)
-    for (c, h, w, k) in [(3, 16, 16, 6), (3, 30, 21, 50), (3, 9, 9, 100)]:
+    for (c, h, w, k) in [(3, 16, 16, 6), (3, 30, 21, 50), (3, 9, 9, 100), (3, 12, 12, 127), (3, 16, 16, 128)]:
         d = (-1 + 2 * torch.rand(c, h, w, k, generator=gen))
         dtd, dtd_inv, d_drg = O.gram_pinv(d.double())
         gm = ops().gram(d.to(DEV))
         close(gm, dtd, 1e-5 * (c * h * w) ** 0.5)
-        out = ops().dict_rightmul(d.to(DEV), dtd_inv.float().to(DEV))
+        out = ops().dict_rightmul(d.to(DEV), dtd_inv.float().to(DEV))      # K = 127/128: > 64 KB of dynamic LDS
         close(out.reshape(-1, k), d_drg.reshape(k, -1).t(), 1e-5)
+        # the K x K inverse on the device (fp64 Gauss-Jordan in LDS) against the fp64 host inverse
+        inv = ops().spd_inverse(dtd.float().to(DEV))
+        ref = torch.linalg.inv(dtd.float().double())
+        close(inv, ref, 2e-6 * float(ref.abs().max()))
+        assert float((inv.double().cpu() @ dtd.float().double() - torch.eye(k, dtype=torch.float64)).abs().max()) < 1e-4
+
+
+def test_pseudo_inverse_k128_ddrague():
+    """ADIL_MAX_ATOMS = 128 through the default inference path (PseudoInverse -> solve_ddrague)."""
+    from dl_attack_on_imagenet_amd import engine
+    from tinynet import make_tinynet
+    gen = torch.Generator().manual_seed(12)
+    d = -1 + 2 * torch.rand(3, 16, 16, 128, generator=gen)
+    x = torch.rand(6, 3, 16, 16, generator=gen)
+    net = make_tinynet(2)
+    adv_o = O.forward_supervised_ddrague(net, x, d, 0.1, 4, "ce")
+    adv = engine.solve_ddrague(net.to(DEV), x.to(DEV), d.to(DEV), 0.1, 4, "ce")
+    close(adv, adv_o, 5e-4)
+
+
+@pytest.mark.parametrize("src_dt,dst_dt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                           (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
+def test_gather_images(src_dt, dst_dt):
+    gen = torch.Generator().manual_seed(8)
+    src = torch.rand(37, 3, 20, 12, generator=gen).to(src_dt)
+    index = torch.tensor([5, 0, 36, 5, 17, 2, 2, 30, 11])                # repeats allowed, any order
+    got = ops().gather_images(src.to(DEV), index.to(DEV), dtype=dst_dt)
+    assert got.dtype == dst_dt and got.shape == (9, 3, 20, 12)
+    assert torch.equal(got.cpu(), src[index].to(dst_dt))                  # bit-exact (RNE conversion, like .to())
+    out = torch.empty(37, 3, 20, 12, dtype=dst_dt, device=DEV)
+    ops().gather_images(src.to(DEV), None, out=out)                       # identity gather = pure cast
+    assert torch.equal(out.cpu(), src.to(dst_dt))
+    big = torch.rand(70, 3, 224, 224, generator=gen)                      # BASELINE image size, more rows than one wave of blocks
+    idx = torch.randperm(70, generator=gen)[:64]
+    assert torch.equal(ops().gather_images(big.to(DEV), idx.to(DEV), dtype=dst_dt).cpu(), big[idx].to(dst_dt))
+
+
+def test_pack_codes_slot_table_round_trip():
+    """adil_pack_codes writes pos[index[b]] = b; adil_adamw_l1ball consumes it and hands it back all -1 — equal to the
+    fill + scatter it replaces, step after step."""
+    gen = torch.Generator().manual_seed(9)
+    n, k, eps = 50, 10, 0.3
+    v = O.project_onto_l1_ball(torch.rand(n, k, generator=gen), eps)
+    va, vb = v.clone().to(DEV), v.clone().to(DEV)
+    ma, sa, mb, sb = (torch.zeros(n, k, device=DEV) for _ in range(4))
+    pos = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+    sch_a, sch_b = ops().AdamWSchedule(0.01), ops().AdamWSchedule(0.01)
+    for step in range(4):
+        idx = torch.randperm(n, generator=gen)[:13].to(DEV)
+        gvb = torch.randn(13, k, generator=gen).to(DEV)
+        vp = ops().pack_codes(va, idx, 13, pos=pos)
+        ref = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+        ref[idx] = torch.arange(13, dtype=torch.int32, device=DEV)
+        assert torch.equal(pos, ref)
+        assert torch.equal(vp[:13, :k], va[idx])
+        ops().adamw_l1ball_(va, gvb, pos, ma, sa, sch_a.next(), eps, reset_pos=True)
+        assert int((pos != -1).sum()) == 0
+        ops().adamw_l1ball_(vb, gvb, ref, mb, sb, sch_b.next(), eps)
+        assert torch.equal(va, vb)
+    ops().adamw_l1ball_(va, None, pos, ma, sa, sch_a.next(), eps, reset_pos=True)     # no row of the batch is ours
+    gv0 = torch.zeros(n, k, device=DEV)
+    ops().adamw_l1ball_(vb, gv0, None, mb, sb, sch_b.next(), eps)
+    assert torch.equal(va, vb)
 
 
 def test_image_metrics():

@@ -188,3 +188,19 @@ def test_g14_uappgd(tag, norm, optim):
     close(attack, z[f"{tag}_attack"], 1e-6)
     close(torch.stack(fooling), z[f"{tag}_fooling"], 0)
     assert [int(f) for f in fooled] == [int(f) for f in z[f"{tag}_train_fooled"]]
+
+
+def test_g15_transfer_performance():
+    """Transfer evaluation (performance.py:183-232) against the reference's own numbers: adversaries from DDrague
+    against the source net, scored on the source and two other targets, sums divided by the dataset size."""
+    z = load_golden("g15_transfer")
+    targets = {name: tinynet_from_npz(z, prefix=f"{name}.") for name in ("src", "t1", "t2")}
+    images, labels, d, n, bs = t(z["images"]), t(z["labels"]), t(z["d"]), len(z["images"]), int(z["batch_size"])
+    perf = O.transfer_performance(
+        lambda x, y: O.forward_supervised_ddrague(targets["src"], x, d, float(z["eps"]), int(z["steps"]), "logits", False,
+                                                  float(z["kappa"])),
+        targets, [(images[i:i + bs], labels[i:i + bs]) for i in range(0, n, bs)], n)
+    for name in targets:
+        close(perf[name]["fooling_rate"], z[f"{name}_fooling_rate"], 1e-6)
+        close(perf[name]["rmse"], z[f"{name}_rmse"], 1e-6)
+        close(perf[name]["mse"], z[f"{name}_mse"], 1e-4)

@@ -7,10 +7,17 @@ import re
 import sys
 
 
+OURS = ("synth", "grad_", "adamw", "pack_codes", "l1ball", "l2ball", "ista", "atom_", "gram", "rightmul", "image_metrics",
+        "sum_partials", "fused", "zstep", "gather_images", "spd_inverse", "transpose_codes", "stem_", "maxpool_fwd",
+        "pw_conv", "conv3x3", "affine_act")
+
+
 def short(name: str) -> str:
     name = name.strip('"')
     name = name.replace("(anonymous namespace)::", "")
     m = re.match(r"(?:void\s+)?((?:\w+::)*)(\w+)[<(]", name)
+    if m and m.group(2).endswith("_kernel") and any(s in m.group(2) for s in OURS):
+        return (m.group(1) + m.group(2))[:70]        # this repo's kernels first: "adamw_clamp_kernel" is not at::clamp
     if "kernel_grouped_conv_bwd_data" in name: return "ck::grouped_conv_bwd_data_xdl"
     if "kernel_grouped_conv_fwd" in name: return "ck::grouped_conv_fwd_xdl"
     if "batch_norm_elementwise_backward_eval" in name: return "at::batch_norm_elementwise_backward_eval"
@@ -35,7 +42,7 @@ def main():
     tot = sum(a[1] for a in agg.values())
     lines = [f"# {title}", "", f"source: `{os.path.basename(path)}` (rocprofv3 --kernel-trace --stats), total GPU kernel time {tot / 1e6:.1f} ms", "",
              "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---:|---:|---:|---:|---:|---:|"]
-    ours = lambda k: any(s in k for s in ("synth", "grad_", "adamw", "pack_codes", "l1ball", "l2ball", "ista", "atom_", "gram", "rightmul", "image_metrics", "sum_partials", "fused"))
+    ours = lambda k: k.endswith("_kernel") and any(s in k for s in OURS)
     items = sorted(agg.items(), key=lambda kv: -kv[1][1])
     shown = [kv for kv in items if ours(kv[0])] + [kv for kv in items if not ours(kv[0])][:12]
     for k, a in shown:
