@@ -65,11 +65,21 @@ def _delta(d, v):
 
 # --------------------------------------------------------------------------------------------------------------- #
 def test_config1_same_backend_fooled_counts_exact():
-    """configs[0]: HIP kernels vs the oracle on the same classifier backend.  Bounds (fp32, stated):
-    fooled counts equal at every one of the 20 iterations; loss within 1e-4 relative; max |V_hip - V_oracle| <= 2e-4
-    (l1 radius 0.0314); max |D v_hip - D v_oracle| <= 1e-3 (perturbation budget 0.0314).  The fraction of dictionary
-    entries that end more than 1e-3 apart is REPORTED, not bounded: a first AdamW step is lr*sign(g), so entries whose
-    gradient is ~0 flip by 2*lr on last-bit differences of g and never meet again."""
+    """configs[0]: HIP kernels vs the oracle on the same classifier backend (oracle code on cuda tensors).
+
+    (1) FREE-RUNNING, 20 iterations each on its own state: fooled counts within one image at every iteration and equal
+        at the end (they were EQUAL AT EVERY ITERATION in 4 of 5 recorded runs; MIOpen's backward is not run-to-run
+        deterministic).  Stated fp32 bounds on the iterates (measured round 2: 1.1e-3, 7.2e-4, 3.8e-3 — the same size as the
+        CPU-oracle leg's, i.e. the drift is the classifier's, not the kernels'): loss within 5e-3 relative, max |dV|
+        <= 2.5e-3, max |D v_hip - D v_oracle| <= 1e-2 (budget eps = 0.0314).  The fraction of dictionary entries ending
+        more than 1e-3 apart is REPORTED, not bounded: AdamW's update is ~lr*sign(g) wherever |g| is small, so an entry
+        whose gradient sign differs in the last bit moves 2*lr apart and never meets again (0.35 here; oracle-CPU vs
+        oracle-GPU shows the same, tools/exp_parity.py -> profiles/r02_exp_parity.txt).
+    (2) TEACHER-FORCED, which is what isolates the kernels: before every one of the 20 iterations the HIP learner is
+        put into the oracle's exact state (D, V, both AdamW moment pairs, step counters), both take ONE step, and the
+        results must agree tightly at every point of the real trajectory: |dD| median <= 1e-6, entries off by more
+        than 1e-4 <= 1 %, max |dV| <= 1e-4, loss within 1e-4 relative (measured: 1.2e-7, 0.29 %, 2.9e-5, 1.3e-5), and the
+        fooled count EQUAL at every one of the 20 points."""
     from dl_attack_on_imagenet_amd import engine, zoo
     from oracle import adil_oracle as O
     n, k, T, eps = 32, 10, 20, 8 / 255
@@ -79,20 +89,42 @@ def test_config1_same_backend_fooled_counts_exact():
     v0 = O.project_onto_l1_ball(torch.rand(n, k, generator=g), eps)
     gpu_model = zoo.build_classifier("resnet18", seed=5, device=DEV)
     batches = [list(range(n))]
+    # (1) free-running
     do, vo, fo, lo = _oracle_run(O, gpu_model, images, d0, v0, T, eps, batches, dev=DEV)
     dh, vh, fh, lh = _hip_run(engine, gpu_model, images, d0, v0, T, eps, batches)
     dd = (dh - do).abs()
     e_v = float((vh - vo).abs().max())
     e_dv = float((_delta(dh, vh) - _delta(do, vo)).abs().max())
     rel_loss = max(abs(a - b) / max(1.0, abs(a)) for a, b in zip(lo, lh))
+    # (2) teacher-forced
+    d, v = d0.clone().to(DEV), v0.clone().to(DEV)
+    sd, sv = O.AdamWState(d, 0.01), O.AdamWState(v, 0.01)
+    x, index = images.to(DEV), torch.arange(n, device=DEV)
+    learner = engine.DictionaryLearner(d.clone(), v.clone(), eps, 0.01, "logits", False, 50.0)
+    forced = dict(dD_median=0.0, frac_dD_gt_1e4=0.0, max_dV=0.0, loss_rel=0.0)
+    for it in range(T):
+        learner.d.copy_(d); learner.v.copy_(v)
+        learner.m_d.copy_(sd.m); learner.s_d.copy_(sd.v); learner.m_v.copy_(sv.m); learner.s_v.copy_(sv.v)
+        learner.sched_d.t, learner.sched_v.t = sd.t, sv.t
+        ls_h, fl_h = learner.step(gpu_model, x, index)
+        ls_o, fl_o = O.learn_step_a(gpu_model, x, index, d, v, sd, sv, eps, "logits", -1.0, 50.0)
+        e = (learner.d - d).abs()
+        forced["dD_median"] = max(forced["dD_median"], float(e.median()))
+        forced["frac_dD_gt_1e4"] = max(forced["frac_dD_gt_1e4"], float((e > 1e-4).float().mean()))
+        forced["max_dV"] = max(forced["max_dV"], float((learner.v - v).abs().max()))
+        forced["loss_rel"] = max(forced["loss_rel"], abs(float(ls_h) - ls_o) / max(1.0, abs(ls_o)))
+        assert int(fl_h) == fl_o, f"teacher-forced step {it}: fooled {int(fl_h)} vs {fl_o}"
     _note("config1_same_backend", dict(fooled_oracle=fo, fooled_hip=fh, max_dV=e_v, max_dDv=e_dv, loss_rel=rel_loss,
                                        dD_max=float(dd.max()), dD_median=float(dd.median()),
-                                       frac_dD_gt_1e3=float((dd > 1e-3).float().mean())))
-    assert fh == fo                                        # bit-exact label decisions, all 20 iterations
-    assert fo[-1] > fo[0]                                  # the attack actually progresses on this workload
-    assert rel_loss <= 1e-4
-    assert e_v <= 2e-4
-    assert e_dv <= 1e-3
+                                       frac_dD_gt_1e3=float((dd > 1e-3).float().mean()), teacher_forced=forced))
+    # free-running label decisions: equal in 4 of the 5 recorded runs (profiles/r02_parity_configs.md); the classifier's
+    # backward is not run-to-run deterministic, so what is asserted is +-1 image per iteration and equality at the end;
+    # the bit-exact check lives in the teacher-forced loop above
+    assert max(abs(a - b) for a, b in zip(fo, fh)) <= 1 and fo[-1] == fh[-1]
+    assert fo[-1] >= 30 and fo[0] <= 4                     # the attack actually works on this workload (2 -> 31 of 32)
+    assert rel_loss <= 5e-3 and e_v <= 2.5e-3 and e_dv <= 1e-2
+    assert forced["dD_median"] <= 1e-6 and forced["frac_dD_gt_1e4"] <= 1e-2
+    assert forced["max_dV"] <= 1e-4 and forced["loss_rel"] <= 1e-4
 
 
 def test_config1_cpu_oracle_leg():
@@ -126,48 +158,82 @@ def test_config1_cpu_oracle_leg():
     assert max(abs(a - b) for a, b in zip(lo, lh)) <= 2e-2 * max(abs(a) for a in lo)
 
 
+class _AsFp32(torch.nn.Module):
+    """A bf16 classifier behind an fp32 interface: what the ORACLE's maths sees when it is wrapped around the product's
+    classifier backend (input rounded to bf16 on the way in, logits / input gradient widened on the way out)."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, x):
+        return self.net(x.to(torch.bfloat16)).float()
+
+
 def test_config2_bf16_fused_resnet50_asr_vs_fp32_oracle():
-    """configs[1] path at a size the fp32 oracle finishes in seconds: ResNet-50 through zoo.FusedResNet (stem / pointwise
-    / 3x3 kernels), bf16 image streams, 50 atoms, 256 images in batches of 64, 10 epochs = 40 steps — against the fp32
-    oracle (plain fp32 ResNet-50, oracle maths) on the same inputs, seeds and batch order.
-    bf16 changes the classifier's activations (8 mantissa bits), so label decisions are NOT expected bit-exact here;
-    the bound is on what north_star asks of the throughput configuration: attack success rate.  Stated tolerance:
-    per-epoch fooling rate within 3 pp, final-epoch ASR within 1.5 pp (256 images: 1 image = 0.39 pp)."""
+    """configs[1] path at a size the oracle finishes in seconds: ResNet-50, 50 atoms, 128 images of 3x224x224 as one batch,
+    40 iterations, eps 8/255, loss 'logits'.  Three legs on identical inputs and seeds:
+      A  fp32 oracle maths + plain fp32 ResNet-50                      (the reference configuration)
+      B  fp32 oracle maths + the product's bf16 classifier (zoo.FusedResNet behind an fp32 interface)
+      C  the product: HIP kernels with bf16 image streams + the same bf16 classifier
+    What bf16 changes is the CLASSIFIER: on a random-init network the logit margins are of the size of bf16 rounding, so
+    labels flip more readily and the fooling rate rises (measured round 2, fooled of 128 after 40 iterations: A 23,
+    B 35-37, C 34-40; plain PyTorch bf16 modules instead of FusedResNet: 28-34) — independent of this repo's kernels, as leg
+    B shows.  C vs B isolates the ADiL kernels' bf16 streams (D, V rounded to bf16 as MFMA operands, x + D v and g stored
+    in bf16).  The trajectories are chaotic (AdamW ~ lr*sign(g)) and the classifier backward is not run-to-run
+    deterministic (+-4 images between identical runs), so the stated tolerances are:
+      free-running   |fooled_C - fooled_B| <= 10 of 128 at every iteration and <= 8 (6 pp) at the end; C and B not weaker
+                     than A by more than 4 images; ASR of each learned (D, V) judged by the SAME fp32 network within 8 pp
+      teacher-forced (C put into B's exact state before every iteration, one step each): fooled counts within 2 images
+                     at each of the 40 points, max |dV| <= 2e-3 (l1 radius 0.0314)."""
     from dl_attack_on_imagenet_amd import engine, zoo
     from oracle import adil_oracle as O
-    n, bsz, k, epochs, eps = 256, 64, 50, 10, 8 / 255
+    n, k, T, eps = 128, 50, 40, 8 / 255
     g = torch.Generator().manual_seed(33)
     images = torch.rand(n, 3, 224, 224, generator=g)
     d0 = -1 + 2 * torch.rand(3, 224, 224, k, generator=g)
     v0 = O.project_onto_l1_ball(torch.rand(n, k, generator=g), eps)
-    batches = [list(range(s, s + bsz)) for s in range(0, n, bsz)]
+    batches = [list(range(n))]
     ref_model = zoo.build_classifier("resnet50", seed=0, device=DEV)                    # fp32, plain PyTorch modules
     fast_model = zoo.build_classifier("resnet50", seed=0, device=DEV, dtype=torch.bfloat16, channels_last=True,
                                       fuse_bn_act=True, fuse_stem=True)
+    wrapped = _AsFp32(fast_model)
+    images16 = images.to(torch.bfloat16).float()             # the bf16-rounded images the product path holds
     with torch.no_grad():
-        lab32 = ref_model(images.to(DEV)).argmax(-1)
-        lab16 = fast_model(images.to(DEV).to(torch.bfloat16)).argmax(-1)
-    agree = float((lab32 == lab16).float().mean())
-    do, vo, fo, _ = _oracle_run(O, ref_model, images, d0, v0, epochs, eps, batches, dev=DEV)
-    dh, vh, fh, _ = _hip_run(engine, fast_model, images, d0, v0, epochs, eps, batches, dtype=torch.bfloat16)
-    per = len(batches)
-    rate_o = [sum(fo[e * per:(e + 1) * per]) / n for e in range(epochs)]
-    rate_h = [sum(fh[e * per:(e + 1) * per]) / n for e in range(epochs)]
+        agree = float((ref_model(images.to(DEV)).argmax(-1) == fast_model(images.to(DEV).to(torch.bfloat16)).argmax(-1)).float().mean())
+    da, va, fa, _ = _oracle_run(O, ref_model, images, d0, v0, T, eps, batches, dev=DEV)
+    db, vb, fb, _ = _oracle_run(O, wrapped, images16, d0, v0, T, eps, batches, dev=DEV)
+    dc, vc, fc, _ = _hip_run(engine, fast_model, images, d0, v0, T, eps, batches, dtype=torch.bfloat16)
 
-    def asr(model, d, v, dtype):                            # performance.py:238-246 on the learned (D, V)
+    def asr_fp32(d, v):                                     # performance.py:238-246 on the learned (D, V), fp32 judge
         x = images.to(DEV)
-        adv = (x + (v @ d.reshape(-1, k).t()).reshape(x.shape)).to(dtype)
+        adv = x + (v @ d.reshape(-1, k).t()).reshape(x.shape)
         with torch.no_grad():
-            return float((model(adv).argmax(-1) != model(x.to(dtype)).argmax(-1)).float().mean())
-    asr_o, asr_h = asr(ref_model, do, vo, torch.float32), asr(fast_model, dh, vh, torch.bfloat16)
-    asr_cross = asr(ref_model, dh, vh, torch.float32)       # the bf16-learned dictionary judged by the fp32 network
-    _note("config2_bf16_asr", dict(clean_label_agreement=agree, fooling_rate_fp32_oracle=rate_o, fooling_rate_bf16_hip=rate_h,
-                                   asr_fp32_oracle=asr_o, asr_bf16_hip=asr_h, asr_bf16_dict_on_fp32_net=asr_cross,
-                                   max_dV=float((vh - vo).abs().max())))
-    assert rate_o[-1] > rate_o[0] + 0.2                     # a working attack, not a flat line
-    assert max(abs(a - b) for a, b in zip(rate_o, rate_h)) <= 0.03
-    assert abs(asr_o - asr_h) <= 0.015
-    assert abs(asr_o - asr_cross) <= 0.015
+            return float((ref_model(adv).argmax(-1) != ref_model(x).argmax(-1)).float().mean())
+    asr = dict(A=asr_fp32(da, va), B=asr_fp32(db, vb), C=asr_fp32(dc, vc))
+    # teacher-forced: C stepped from B's state at every point of B's trajectory
+    d, v = d0.clone().to(DEV), v0.clone().to(DEV)
+    sd, sv = O.AdamWState(d, 0.01), O.AdamWState(v, 0.01)
+    x32, x16, index = images16.to(DEV), images.to(DEV).to(torch.bfloat16), torch.arange(n, device=DEV)
+    learner = engine.DictionaryLearner(d.clone(), v.clone(), eps, 0.01, "logits", False, 50.0)
+    tf_fooled, tf_dv = [], 0.0
+    for _ in range(T):
+        learner.d.copy_(d); learner.v.copy_(v)
+        learner.m_d.copy_(sd.m); learner.s_d.copy_(sd.v); learner.m_v.copy_(sv.m); learner.s_v.copy_(sv.v)
+        learner.sched_d.t, learner.sched_v.t = sd.t, sv.t
+        _, fl_c = learner.step(fast_model, x16, index)
+        _, fl_b = O.learn_step_a(wrapped, x32, index, d, v, sd, sv, eps, "logits", -1.0, 50.0)
+        tf_fooled.append((int(fl_c), int(fl_b)))
+        tf_dv = max(tf_dv, float((learner.v - v).abs().max()))
+    _note("config2_bf16_asr", dict(clean_label_agreement=agree, fooled_A_fp32=fa, fooled_B_oracle_on_bf16_net=fb,
+                                   fooled_C_product=fc, asr_judged_by_fp32_net=asr, teacher_forced_fooled_C_B=tf_fooled,
+                                   teacher_forced_max_dV=tf_dv))
+    assert fa[-1] >= 15                                     # a working attack on this workload, not a flat line
+    assert max(abs(c - b_) for c, b_ in zip(fc, fb)) <= 10 and abs(fc[-1] - fb[-1]) <= 8
+    assert fc[-1] >= fa[-1] - 4 and fb[-1] >= fa[-1] - 4
+    assert max(asr.values()) - min(asr.values()) <= 0.08
+    assert max(abs(c - b_) for c, b_ in tf_fooled) <= 2
+    assert tf_dv <= 2e-3
 
 
 @pytest.mark.parametrize("name,k,b", [("densenet121", 50, 16), ("vit_b_16", 100, 16)])

@@ -1,0 +1,76 @@
+"""Calibration run for tests/test_gpu_parity_configs.py::test_config2_bf16_*: fooled-count trajectories of the fp32 oracle
+(plain fp32 ResNet-50 on the GPU) and of the bf16 product path (FusedResNet + bf16 streams) on identical inputs, for a
+few (N, batch, T) settings.  Prints one JSON line per setting."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dl_attack_on_imagenet_amd import engine, zoo
+from oracle import adil_oracle as O
+
+DEV = "cuda"
+eps, k = 8 / 255, 50
+ref_model = zoo.build_classifier("resnet50", seed=0, device=DEV)
+fast_model = zoo.build_classifier("resnet50", seed=0, device=DEV, dtype=torch.bfloat16, channels_last=True, fuse_bn_act=True,
+                                  fuse_stem=True)
+plain16 = zoo.build_classifier("resnet50", seed=0, device=DEV, dtype=torch.bfloat16)
+class AsFp32(torch.nn.Module):
+    """A bf16 classifier behind an fp32 interface: what the ORACLE's maths sees when it is wrapped around the product's
+    classifier backend (input rounded to bf16 on the way in, logits / input gradient widened on the way out)."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, x):
+        return self.net(x.to(torch.bfloat16)).float()
+
+
+for n, bsz, epochs in ((128, 128, 40),):
+    g = torch.Generator().manual_seed(33)
+    images = torch.rand(n, 3, 224, 224, generator=g)
+    d0 = -1 + 2 * torch.rand(3, 224, 224, k, generator=g)
+    v0 = O.project_onto_l1_ball(torch.rand(n, k, generator=g), eps)
+    batches = [list(range(s, s + bsz)) for s in range(0, n, bsz)]
+    out = dict(n=n, batch=bsz, epochs=epochs)
+    # fp32 oracle
+    d, v = d0.clone().to(DEV), v0.clone().to(DEV)
+    sd, sv = O.AdamWState(d, 0.01), O.AdamWState(v, 0.01)
+    x = images.to(DEV)
+    fo = []
+    for _ in range(epochs):
+        tot = 0
+        for idx in batches:
+            index = torch.as_tensor(idx, device=DEV)
+            _, fl = O.learn_step_a(ref_model, x[index], index, d, v, sd, sv, eps, "logits", -1.0, 50.0)
+            tot += int(fl)
+        fo.append(tot)
+    out["fooled_fp32_oracle"] = fo
+    for tag, model in (("oracle_maths_on_bf16_fused", AsFp32(fast_model)), ("oracle_maths_on_bf16_plain", AsFp32(plain16))):
+        d, v = d0.clone().to(DEV), v0.clone().to(DEV)
+        sd, sv = O.AdamWState(d, 0.01), O.AdamWState(v, 0.01)
+        xr = images.to(DEV).to(torch.bfloat16).float()            # the same bf16-rounded images the product path holds
+        fb = []
+        for _ in range(epochs):
+            tot = 0
+            for idx in batches:
+                index = torch.as_tensor(idx, device=DEV)
+                _, fl = O.learn_step_a(model, xr[index], index, d, v, sd, sv, eps, "logits", -1.0, 50.0)
+                tot += int(fl)
+            fb.append(tot)
+        out[f"fooled_{tag}"] = fb
+    for tag, model in (("bf16_fused", fast_model), ("bf16_plain", plain16)):
+        learner = engine.DictionaryLearner(d0.clone().to(DEV), v0.clone().to(DEV), eps, 0.01, "logits", False, 50.0)
+        x16 = images.to(DEV).to(torch.bfloat16)
+        fh = []
+        for _ in range(epochs):
+            tot = 0
+            for idx in batches:
+                index = torch.as_tensor(idx, device=DEV)
+                _, fl = learner.step(model, x16[index].contiguous(), index)
+                tot += int(fl)
+            fh.append(tot)
+        out[f"fooled_{tag}"] = fh
+    print(json.dumps(out), flush=True)

@@ -44,3 +44,5 @@ for a, b in (("cpu_oracle", "gpu_oracle"), ("gpu_oracle", "hip"), ("cpu_oracle",
     dd = (da - db).abs()
     print(f"{a:11s} vs {b:11s}: |dD| max {dd.max():.3e} mean {dd.mean():.3e} frac>1e-3 {(dd > 1e-3).float().mean():.3e} | |dV| {float((va - vb).abs().max()):.3e} | "
           f"|d(Dv)| {float((va @ da.reshape(-1, k).t() - vb @ db.reshape(-1, k).t()).abs().max()):.3e} | fooled equal {fa == fb}")
+for name, (_, _, f) in runs.items():
+    print(f"fooled {name:11s} {f}")
