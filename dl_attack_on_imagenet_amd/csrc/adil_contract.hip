@@ -5,11 +5,11 @@
 //
 // Both kernels are HBM-bound streaming kernels; MFMA is used only so that the small dense contractions do not
 // become ALU-bound.  One code path per stream type, selected by Mma<T>:
-//   T = float  : v_mfma_f32_32x32x2_f32  (exact fp32 fmaf chain; the parity path)
+//   T = float  : six v_mfma_f32_32x32x16_bf16 on a three-way bf16 split of each fp32 operand (fp32-grade; the parity path)
 //   T = bf16   : v_mfma_f32_32x32x16_bf16 (D and V rounded to bf16 on the fly, fp32 accumulate; the throughput path)
 // Every operand fragment covers a "k-group" of 16 reduction indices: lane (r = lane&31, h = lane>>5) supplies the
 // 8 consecutive indices 16g + 8h + j, j = 0..7, of row/column r — identical for both instruction shapes, so the
-// data movement is shared and only Mma<T>::mma differs (8 f32 MFMAs vs 1 bf16 MFMA per k-group).
+// data movement is shared and only Mma<T>::mma differs (6 split MFMAs vs 1 bf16 MFMA per k-group).
 // C/D layout of a 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include "adil_common.h"
 
@@ -20,31 +20,71 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <typename T> struct Mma;
 
+// fp32 operands on the bf16 matrix pipe.  gfx950 has no xf32 MFMA and v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16
+// rate, which made every fp32 contraction MFMA-bound (grad 272 us = 0.17 of the HBM roof in round 1).  Each fp32 value is
+// split into three bf16 pieces, x = h + m + l exactly to 2^-24 relative (h = rne(x), m = rne(x - h), l = rne(x - h - m);
+// the subtractions are exact), and a product is formed from the six piece products whose weight is >= 2^-16 relative:
+//     a b = ah bh + (ah bm + am bh) + (am bm + ah bl + al bh)  + O(2^-24 |a b|)
+// — six v_mfma_f32_32x32x16_bf16 per k-group of 16 instead of eight 32x32x2_f32: 192 vs 512 MFMA cycles, fp32
+// accumulation, and an error per product of the size of one fp32 rounding (bf16 x bf16 products are exact in fp32).
+// Small terms are issued first so that they are not absorbed by a large partial sum.
 template <> struct Mma<float> {
-    struct Frag { float v[8]; };
+    struct Frag { bf16x8 h, m, l; };
     typedef float Elem;                         // element type of operands staged in LDS / workspace
     static constexpr int PAD = 4;               // LDS row padding (elements): (stride/4) odd -> conflict-free b128
     static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+        h = pack2_bf16(x0, x1);
+        float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+        m = pack2_bf16(r0, r1);
+        r0 -= __uint_as_float(m << 16);
+        r1 -= __uint_as_float(m & 0xffff0000u);
+        l = pack2_bf16(r0, r1);
     }
     static __device__ __forceinline__ Frag from8(const float (&f)[8]) {
-        Frag r;
+        u32x4 h, m, l;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.v[j] = f[j];
+        for (int j = 0; j < 4; ++j) {
+            unsigned hj, mj, lj;
+            split2(f[2 * j], f[2 * j + 1], hj, mj, lj);
+            h[j] = hj; m[j] = mj; l[j] = lj;
+        }
+        Frag r;
+        r.h = __builtin_bit_cast(bf16x8, h);
+        r.m = __builtin_bit_cast(bf16x8, m);
+        r.l = __builtin_bit_cast(bf16x8, l);
         return r;
     }
     static __device__ __forceinline__ Elem to_elem(float x) { return x; }
     static __device__ __forceinline__ void touch(Frag& f) {          // make the value opaque: its loads must have landed
-#pragma unroll
-        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(f.v[j]));
+        u32x4 h = __builtin_bit_cast(u32x4, f.h), m = __builtin_bit_cast(u32x4, f.m), l = __builtin_bit_cast(u32x4, f.l);
+        asm volatile("" : "+v"(h), "+v"(m), "+v"(l));
+        f.h = __builtin_bit_cast(bf16x8, h);
+        f.m = __builtin_bit_cast(bf16x8, m);
+        f.l = __builtin_bit_cast(bf16x8, l);
     }
     static __device__ __forceinline__ Frag load8(const Elem* p) {      // 8 consecutive elements, 16-B aligned
         const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
-        Frag r;
-        r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
-        r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
-        return r;
+        const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        return from8(f);
+    }
+    // long-lived fragments are kept un-split (8 registers instead of 12) and expanded where they are used
+    struct Raw { float v[8]; };
+    static __device__ __forceinline__ Raw load8_raw(const Elem* p) {
+        const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
+        return Raw{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+    }
+    static __device__ __forceinline__ Frag expand(const Raw& r) { return from8(r.v); }
+    static __device__ __forceinline__ void touch_raw(Raw& r) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(r.v[j]));
     }
 };
 
@@ -68,6 +108,66 @@ template <> struct Mma<bf16_t> {
         f = __builtin_bit_cast(Frag, t);
     }
     static __device__ __forceinline__ Frag load8(const Elem* p) { return *reinterpret_cast<const Frag*>(p); }
+    typedef Frag Raw;
+    static __device__ __forceinline__ Raw load8_raw(const Elem* p) { return load8(p); }
+    static __device__ __forceinline__ Frag expand(const Raw& r) { return r; }
+    static __device__ __forceinline__ void touch_raw(Raw& r) { touch(r); }
+};
+
+// ---- the dictionary operand staged in LDS ------------------------------------------------------------------- //
+// Always bf16 elements, row stride n + DPAD.  bf16 streams keep one plane (D rounded to bf16); fp32 streams keep the
+// THREE planes h, m, l of Mma<float>'s split, written once per workgroup when the slice / tile is staged: the shared
+// operand is then read by every wave as three ds_read_b128 with no conversion work (splitting it at each use made
+// the fp32 kernels VALU-bound: 44 VALU per fragment, re-done by every wave for every batch block).
+#define DPAD 8
+template <typename T> struct DImg;
+template <> struct DImg<bf16_t> {
+    static constexpr int PLANES = 1;
+    static __device__ __forceinline__ void put(bf16_t* img, int off, int plane, float v) { (void)plane; img[off] = f32_to_bf16(v); }
+    static __device__ __forceinline__ void put2(bf16_t* img, int off, int plane, const float (&f)[2]) {
+        (void)plane;
+        *reinterpret_cast<unsigned*>(img + off) = pack2_bf16(f[0], f[1]);
+    }
+    static __device__ __forceinline__ void put4(bf16_t* img, int off, int plane, const float (&f)[4]) {
+        (void)plane;
+        *reinterpret_cast<u32x2*>(img + off) = u32x2{pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3])};
+    }
+    static __device__ __forceinline__ bf16x8 load8(const bf16_t* p, int plane) {
+        (void)plane;
+        return *reinterpret_cast<const bf16x8*>(p);
+    }
+};
+template <> struct DImg<float> {
+    static constexpr int PLANES = 3;
+    static __device__ __forceinline__ void put2(bf16_t* img, int off, int plane, const float (&f)[2]) {
+        unsigned h, m, l;
+        Mma<float>::split2(f[0], f[1], h, m, l);
+        *reinterpret_cast<unsigned*>(img + off) = h;
+        *reinterpret_cast<unsigned*>(img + off + plane) = m;
+        *reinterpret_cast<unsigned*>(img + off + 2 * plane) = l;
+    }
+    static __device__ __forceinline__ void put4(bf16_t* img, int off, int plane, const float (&f)[4]) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        Mma<float>::split2(f[0], f[1], h0, m0, l0);
+        Mma<float>::split2(f[2], f[3], h1, m1, l1);
+        *reinterpret_cast<u32x2*>(img + off) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(img + off + plane) = u32x2{m0, m1};
+        *reinterpret_cast<u32x2*>(img + off + 2 * plane) = u32x2{l0, l1};
+    }
+    static __device__ __forceinline__ void put(bf16_t* img, int off, int plane, float v) {
+        unsigned h, m, l;
+        Mma<float>::split2(v, 0.0f, h, m, l);
+        img[off] = (bf16_t)(h & 0xffffu);
+        img[off + plane] = (bf16_t)(m & 0xffffu);
+        img[off + 2 * plane] = (bf16_t)(l & 0xffffu);
+    }
+    static __device__ __forceinline__ Mma<float>::Frag load8(const bf16_t* p, int plane) {
+        Mma<float>::Frag r;
+        r.h = *reinterpret_cast<const bf16x8*>(p);
+        r.m = *reinterpret_cast<const bf16x8*>(p + plane);
+        r.l = *reinterpret_cast<const bf16x8*>(p + 2 * plane);
+        return r;
+    }
 };
 
 // ---- image-stream access: N consecutive pixels of one row as floats ---------------------------------------- //
@@ -248,10 +348,11 @@ __device__ __forceinline__ int c_row(int reg, int h) { return (reg & 3) + 8 * (r
 
 template <typename T, bool XACC, bool FAST>
 __device__ __forceinline__ void synth_sweep(const T* __restrict__ x, const float* __restrict__ vp, T* __restrict__ out,
-                                            const typename Mma<T>::Elem* sd, int B, int P, int Kp, int Ks, int p0,
+                                            const bf16_t* sd, int B, int P, int Kp, int Ks, int p0,
                                             float delta_clamp, int pixel_clamp, int w, int c, int h) {
     using M = Mma<T>;
     using Frag = typename M::Frag;
+    const int plane = SYNTH_TILE * Ks;
     const int NG = Kp >> 4;
     const int nbb = (B + 31) >> 5;
     const int px = p0 + 4 * c;
@@ -275,7 +376,7 @@ __device__ __forceinline__ void synth_sweep(const T* __restrict__ x, const float
             const Frag an = frag_from_f32x8<T>(arow + 16 * gn);                            // prefetch the next k-group
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const Frag bf = M::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h);
+                const Frag bf = DImg<T>::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h, plane);
                 M::mma(acc[t], a, bf);
             }
             a = an;
@@ -341,12 +442,13 @@ __device__ __forceinline__ void synth_store_buf(const f32x16 (&acc)[4], buf_rsrc
 #define SYNTH_HOIST 4
 template <typename T, bool XACC>
 __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const float* __restrict__ vp,
-                                                T* __restrict__ out, const typename Mma<T>::Elem* sd, int B, int P,
+                                                T* __restrict__ out, const bf16_t* sd, int B, int P,
                                                 int Kp, int Ks, int p0, float delta_clamp, int pixel_clamp, int w, int c,
                                                 int h) {
     using M = Mma<T>;
     using Frag = typename M::Frag;
     using BP = BufPx<T>;
+    const int plane = SYNTH_TILE * Ks;
     const int NG = Kp >> 4;
     const int nbb = (B + 31) >> 5;
     const unsigned rowb = (unsigned)P * (unsigned)sizeof(T);
@@ -395,13 +497,13 @@ __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const f
         for (int g = 0; g < SYNTH_HOIST; ++g) {
             if (g < NG) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) M::mma(acc[t], a[g], M::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h));
+                for (int t = 0; t < 4; ++t) M::mma(acc[t], a[g], DImg<T>::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h, plane));
             }
         }
         for (int g = SYNTH_HOIST; g < NG; ++g) {                                         // K > 64
             const Frag ag = frag_from_f32x8<T>(arow + 16 * g);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) M::mma(acc[t], ag, M::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h));
+            for (int t = 0; t < 4; ++t) M::mma(acc[t], ag, DImg<T>::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h, plane));
         }
         if (pixel_clamp)                                                                  // uniform: one branch per block
             synth_store_buf<T, XACC, true>(acc, rx, ro, voff, rowb, delta_clamp);
@@ -410,20 +512,13 @@ __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const f
     }
 }
 
-template <typename T, bool XACC, bool FAST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void synth_mfma_kernel(const T* __restrict__ x, const float* __restrict__ d,
-                                                         const float* __restrict__ vp, T* __restrict__ out, int B,
-                                                         int P, int K, int Kp, float delta_clamp, int pixel_clamp,
-                                                         int tile0) {
-    using M = Mma<T>;
-    using E = typename M::Elem;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    E* sd = reinterpret_cast<E*>(smem_raw);
-    const int Ks = Kp + M::PAD;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
-    // consecutive tiles go to consecutive workgroups, i.e. round-robin over the 8 XCDs: for this pure stream that is
-    // 8 % faster than giving each XCD one contiguous range of tiles (measured)
-    const int p0 = (tile0 + blockIdx.x) * SYNTH_TILE;
+// The 128-pixel slice of the dictionary operand (D for synth, D_dagger^T for the z-step) -> LDS planes of DImg<T>,
+// tile-major rows (pixel r at row (r&3)*32 + (r>>2)), padded atoms zeroed.  256 threads.
+template <typename T, bool FAST>
+__device__ __forceinline__ void fill_dict_slice(const float* __restrict__ d, bf16_t* sd, int p0, int P, int K, int Kp,
+                                                int Ks, int tid) {
+    using DI = DImg<T>;
+    const int plane = SYNTH_TILE * Ks;
     if constexpr (FAST) {
         // D slice -> LDS.  The slice (128 pixels x K atoms) is one contiguous, 16-byte aligned run of 32*K float4:
         // every thread issues up to 8 independent 16-byte loads before the first conversion, so the fill costs ONE
@@ -448,17 +543,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                     int k = i - r * K;
                     const float e4[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
                     if ((K & 3) == 0) {                              // uniform: the quad stays inside one row
-                        lds_put<E, 4>(sd + ((r & 3) * 32 + (r >> 2)) * Ks + k, e4);
+                        DI::put4(sd, ((r & 3) * 32 + (r >> 2)) * Ks + k, plane, e4);
                     } else if ((K & 1) == 0) {                       // pairs stay inside one row
                         const float lo[2] = {e4[0], e4[1]}, hi[2] = {e4[2], e4[3]};
-                        lds_put<E, 2>(sd + ((r & 3) * 32 + (r >> 2)) * Ks + k, lo);
+                        DI::put2(sd, ((r & 3) * 32 + (r >> 2)) * Ks + k, plane, lo);
                         k += 2;
                         if (k == K) { k = 0; ++r; }
-                        lds_put<E, 2>(sd + ((r & 3) * 32 + (r >> 2)) * Ks + k, hi);
+                        DI::put2(sd, ((r & 3) * 32 + (r >> 2)) * Ks + k, plane, hi);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            sd[((r & 3) * 32 + (r >> 2)) * Ks + k] = M::to_elem(e4[e]);
+                            DI::put(sd, ((r & 3) * 32 + (r >> 2)) * Ks + k, plane, e4[e]);
                             if (++k == K) { k = 0; ++r; }
                         }
                     }
@@ -466,7 +561,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
             }
         }
         for (int k = K + (tid & 1); k < Kp; k += 2)                   // zero the padded atoms of row tid/2
-            sd[(((tid >> 1) & 3) * 32 + (tid >> 3)) * Ks + k] = M::to_elem(0.0f);
+            DI::put(sd, (((tid >> 1) & 3) * 32 + (tid >> 3)) * Ks + k, plane, 0.0f);
     } else {
         // element-wise fill with pixel / atom guards: eight independent loads are issued before the first conversion
         for (int i0 = tid; i0 < SYNTH_TILE * Kp; i0 += 256 * 8) {
@@ -483,10 +578,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + 256 * u;
                 const int r = i / Kp, k = i - r * Kp;
-                sd[((r & 3) * 32 + (r >> 2)) * Ks + k] = M::to_elem(val[u]);
+                DI::put(sd, ((r & 3) * 32 + (r >> 2)) * Ks + k, plane, val[u]);
             }
         }
     }
+}
+
+template <typename T, bool XACC, bool FAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void synth_mfma_kernel(const T* __restrict__ x, const float* __restrict__ d,
+                                                         const float* __restrict__ vp, T* __restrict__ out, int B,
+                                                         int P, int K, int Kp, float delta_clamp, int pixel_clamp,
+                                                         int tile0) {
+    using DI = DImg<T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sd = reinterpret_cast<bf16_t*>(smem_raw);            // [PLANES][128][Ks] bf16
+    const int Ks = Kp + DPAD;
+    const int plane = SYNTH_TILE * Ks;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    // consecutive tiles go to consecutive workgroups, i.e. round-robin over the 8 XCDs: for this pure stream that is
+    // 8 % faster than giving each XCD one contiguous range of tiles (measured)
+    const int p0 = (tile0 + blockIdx.x) * SYNTH_TILE;
+    fill_dict_slice<T, FAST>(d, sd, p0, P, K, Kp, Ks, tid);
     __syncthreads();
     if constexpr (FAST)
         synth_sweep_buf<T, XACC>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp,
@@ -501,6 +613,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
 // is formed in the MFMA accumulators and consumed on the spot by AdamW(z) + clamp(+-eps) + max|dz| — it is never
 // written to HBM.  Same workgroup / fragment layout as synth_mfma_kernel; z, m, s are fp32 B x P.
 // =========================================================================================================== //
+// AdamW(z) + clamp + max|dz| on one 16-byte group of a row; gz = the matching accumulator entries
+__device__ __forceinline__ float zstep_quad(float (&zv)[4], float (&mv)[4], float (&sv)[4], const f32x16 (&acc)[4], int reg,
+                                            const AdamWHyper& hy, float lo, float hi) {
+    float dmax = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float q = adamw_elem(zv[t], acc[t][reg], mv[t], sv[t], hy);
+        q = fminf(fmaxf(q, lo), hi);
+        dmax = fmaxf(dmax, fabsf(q - zv[t]));
+        zv[t] = q;
+    }
+    return dmax;
+}
+
 template <bool FAST>
 __global__ __launch_bounds__(256) void zstep_mfma_kernel(float* __restrict__ z, float* __restrict__ m,
                                                          float* __restrict__ sq, const float* __restrict__ d,
@@ -509,71 +635,109 @@ __global__ __launch_bounds__(256) void zstep_mfma_kernel(float* __restrict__ z, 
                                                          int tile0) {
     using M = Mma<float>;
     using Frag = M::Frag;
+    using DI = DImg<float>;
+    using BP = BufPx<float>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* sd = reinterpret_cast<float*>(smem_raw);
-    const int Ks = Kp + M::PAD;
+    bf16_t* sd = reinterpret_cast<bf16_t*>(smem_raw);            // [3][128][Ks] bf16: the h, m, l planes of D_dagger
+    const int Ks = Kp + DPAD;
+    const int plane = SYNTH_TILE * Ks;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int p0 = (tile0 + blockIdx.x) * SYNTH_TILE;
-    for (int i0 = tid; i0 < SYNTH_TILE * Kp; i0 += 256 * 8) {
-        float val[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 256 * u;
-            const int r = i / Kp, k = i - r * Kp;
-            const int p = p0 + r;
-            const float ok = ((p < P) && (k < K)) ? 1.0f : 0.0f;
-            val[u] = d[(size_t)(p < P ? p : P - 1) * K + (k < K ? k : K - 1)] * ok;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 256 * u;
-            const int r = i / Kp, k = i - r * Kp;
-            sd[((r & 3) * 32 + (r >> 2)) * Ks + k] = val[u];
-        }
-    }
+    fill_dict_slice<float, FAST>(d, sd, p0, P, K, Kp, Ks, tid);
     __syncthreads();
     const int NG = Kp >> 4;
     const int nbb = (B + 31) >> 5;
     const int px = p0 + 4 * c;
     float dmax = 0.0f;
-    for (int bb = w; bb < nbb; bb += 4) {
-        const int b0 = bb << 5;
-        f32x16 acc[4];
+    if constexpr (FAST) {
+        // Aligned interior: the six streams (z, m, s in and out) go through raw buffer instructions in groups of two
+        // rows — 6 to 12 independent 16-byte loads per lane in flight, the next group requested before the current one
+        // is consumed, the first group before the MFMA phase — so the kernel streams instead of paying one memory round
+        // trip per row (round 1: 469 us for 1.88 GB).  Rows >= B: loads return 0, stores are dropped by the descriptor.
+        const unsigned rowb = (unsigned)P * 4u;
+        const int voff = (int)((unsigned)(4 * h) * rowb) + (p0 + 4 * c) * 4;
+        for (int bb = __builtin_amdgcn_readfirstlane(w); bb < nbb; bb += 4) {
+            const int b0 = bb << 5;
+            const int rows = B - b0 < 32 ? B - b0 : 32;
+            const unsigned bytes = (unsigned)rows * rowb;
+            const buf_rsrc rz = block_rsrc(z + (size_t)b0 * P, bytes), rm = block_rsrc(m + (size_t)b0 * P, bytes),
+                           rs = block_rsrc(sq + (size_t)b0 * P, bytes);
+            constexpr int GR = 2;                                // rows per group
+            BP::Raw zr[2][GR], mr[2][GR], sr[2][GR];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        const float* arow = vp + (size_t)(b0 + c) * Kp + 8 * h;
-        Frag a = frag_from_f32x8<float>(arow);
-        for (int g = 0; g < NG; ++g) {
-            const int gn = (g + 1 < NG) ? g + 1 : g;
-            const Frag an = frag_from_f32x8<float>(arow + 16 * gn);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const Frag bf = M::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h);
-                M::mma(acc[t], a, bf);
+            for (int j = 0; j < GR; ++j) {
+                const int soff = (int)((unsigned)c_row(j, 0) * rowb);
+                zr[0][j] = BP::load(rz, voff, soff); mr[0][j] = BP::load(rm, voff, soff); sr[0][j] = BP::load(rs, voff, soff);
             }
-            a = an;
+            f32x16 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+            const float* arow = vp + (size_t)(b0 + c) * Kp + 8 * h;
+            Frag a = frag_from_f32x8<float>(arow);
+            for (int g = 0; g < NG; ++g) {
+                const int gn = (g + 1 < NG) ? g + 1 : g;
+                const Frag an = frag_from_f32x8<float>(arow + 16 * gn);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) M::mma(acc[t], a, DI::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h, plane));
+                a = an;
+            }
+#pragma unroll
+            for (int grp = 0; grp < 16 / GR; ++grp) {
+                const int cur = grp & 1, nxt = cur ^ 1;
+                if (grp + 1 < 16 / GR) {
+#pragma unroll
+                    for (int j = 0; j < GR; ++j) {
+                        const int soff = (int)((unsigned)c_row(GR * (grp + 1) + j, 0) * rowb);
+                        zr[nxt][j] = BP::load(rz, voff, soff); mr[nxt][j] = BP::load(rm, voff, soff);
+                        sr[nxt][j] = BP::load(rs, voff, soff);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);               // keep the next group's requests ahead of this group's use
+#pragma unroll
+                for (int j = 0; j < GR; ++j) {
+                    const int reg = GR * grp + j;
+                    const int soff = (int)((unsigned)c_row(reg, 0) * rowb);
+                    float zv[4], mv[4], sv[4];
+                    BP::unpack(zr[cur][j], zv); BP::unpack(mr[cur][j], mv); BP::unpack(sr[cur][j], sv);
+                    dmax = fmaxf(dmax, zstep_quad(zv, mv, sv, acc, reg, hy, lo, hi));
+                    BP::store(rz, voff, soff, zv); BP::store(rm, voff, soff, mv); BP::store(rs, voff, soff, sv);
+                }
+            }
         }
+    } else {
+        for (int bb = w; bb < nbb; bb += 4) {
+            const int b0 = bb << 5;
+            f32x16 acc[4];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = b0 + c_row(reg, h);
-            const size_t ro = (size_t)(row < B ? row : B - 1) * P;        // rows >= B: valid address, never stored
-            float zv[4], mv[4], sv[4];
-            load_px<float, 4, FAST>(z + ro, px, P, zv);
-            load_px<float, 4, FAST>(m + ro, px, P, mv);
-            load_px<float, 4, FAST>(sq + ro, px, P, sv);
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float q = adamw_elem(zv[t], acc[t][reg], mv[t], sv[t], hy);
-                q = fminf(fmaxf(q, lo), hi);
-                if (row < B && (FAST || px + t < P)) dmax = fmaxf(dmax, fabsf(q - zv[t]));
-                zv[t] = q;
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+            const float* arow = vp + (size_t)(b0 + c) * Kp + 8 * h;
+            for (int g = 0; g < NG; ++g) {
+                const Frag a = frag_from_f32x8<float>(arow + 16 * g);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) M::mma(acc[t], a, DI::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h, plane));
             }
-            if (row < B) {
-                store_px4<float, FAST>(z + ro, px, P, zv);
-                store_px4<float, FAST>(m + ro, px, P, mv);
-                store_px4<float, FAST>(sq + ro, px, P, sv);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = b0 + c_row(reg, h);
+                const size_t ro = (size_t)(row < B ? row : B - 1) * P;        // rows >= B: valid address, never stored
+                float zv[4], mv[4], sv[4];
+                load_px<float, 4, false>(z + ro, px, P, zv);
+                load_px<float, 4, false>(m + ro, px, P, mv);
+                load_px<float, 4, false>(sq + ro, px, P, sv);
+                const float zold[4] = {zv[0], zv[1], zv[2], zv[3]};
+                (void)zstep_quad(zv, mv, sv, acc, reg, hy, lo, hi);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (row < B && px + t < P) dmax = fmaxf(dmax, fabsf(zv[t] - zold[t]));
+                if (row < B) {
+                    store_px4<float, false>(z + ro, px, P, zv);
+                    store_px4<float, false>(m + ro, px, P, mv);
+                    store_px4<float, false>(sq + ro, px, P, sv);
+                }
             }
         }
     }
@@ -697,17 +861,16 @@ __device__ __forceinline__ void gv_load_d(const float* __restrict__ d, int tile,
     }
 }
 template <typename T, int AT, int NW, bool FAST>
-__device__ __forceinline__ void gv_write_d(typename Mma<T>::Elem* dst, int tile, int P, int K, int tid,
+__device__ __forceinline__ void gv_write_d(bf16_t* dst, int tile, int P, int K, int tid,
                                            const float (&dreg)[(GV_TW * AT * 32 + NW * 64 - 1) / (NW * 64)]) {
-    using M = Mma<T>;
-    constexpr int KA = AT * 32, NT = NW * 64, DPT = (GV_TW * KA + NT - 1) / NT, GS = GV_TW + M::PAD;
+    constexpr int KA = AT * 32, NT = NW * 64, DPT = (GV_TW * KA + NT - 1) / NT, GD = GV_TW + DPAD;
 #pragma unroll
     for (int e = 0; e < DPT; ++e) {
         const int i = tid + e * NT;
         const int px = i / KA, a = i - px * KA;
         const int pix = tile * GV_TW + px;
         const float m = (a < K && (FAST || pix < P)) ? 1.0f : 0.0f;   // atom / pixel tails: multiply, never a select
-        if (px < GV_TW) dst[a * GS + px] = M::to_elem(dreg[e] * m);
+        if (px < GV_TW) DImg<T>::put(dst, a * GD + px, KA * GD, dreg[e] * m);
     }
 }
 // this wave's 32 x 64 block of g: NLD fully coalesced 16-byte loads per lane
@@ -755,10 +918,11 @@ __global__ __launch_bounds__(NW * 64) void grad_v_mfma_kernel(const T* __restric
     constexpr int NLD = 32 / RPI;                                // load instructions per 32-row block
     constexpr int NT = NW * 64;
     constexpr int DPT = (GV_TW * KA + NT - 1) / NT;              // D-tile elements per thread
+    constexpr int GD = GV_TW + DPAD, DPL = KA * GD, DBUF = DImg<T>::PLANES * DPL;   // D tile: planes of [KA][GD] bf16
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    E* sdt = reinterpret_cast<E*>(smem_raw);                     // [2][KA][GS]  transposed D tile, double buffered
+    bf16_t* sdt = reinterpret_cast<bf16_t*>(smem_raw);           // [2][PLANES][KA][GD]  transposed D tile, double buffered
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
-    E* sg = sdt + 2 * KA * GS + (size_t)w * 32 * GS;             // this wave's [32][GS] image of its g block
+    E* sg = reinterpret_cast<E*>(sdt + 2 * DBUF) + (size_t)w * 32 * GS;   // this wave's [32][GS] image of its g block
     const int t0 = tile_begin + blockIdx.x * tiles_per_wg;
     const int t1 = min(tile_end, t0 + tiles_per_wg);
     const int b0 = w << 5;
@@ -790,18 +954,18 @@ __global__ __launch_bounds__(NW * 64) void grad_v_mfma_kernel(const T* __restric
         }
         lds_barrier();                                          // D[buf] complete; everyone is done reading D[buf^1]
         if (active) {
-            const E* sdb = sdt + buf * KA * GS;
+            const bf16_t* sdb = sdt + buf * DBUF;
 #pragma unroll
             for (int g3 = 0; g3 < GV_TW / 16; ++g3) {
                 const Frag a = M::load8(sg + c * GS + 16 * g3 + 8 * h);
 #pragma unroll
                 for (int at = 0; at < AT; ++at) {
-                    const Frag bfr = M::load8(sdb + (at * 32 + c) * GS + 16 * g3 + 8 * h);
+                    const Frag bfr = DImg<T>::load8(sdb + (at * 32 + c) * GD + 16 * g3 + 8 * h, DPL);
                     M::mma(accv[at], a, bfr);
                 }
             }
         }
-        if (more) gv_write_d<T, AT, NW, FAST>(sdt + (buf ^ 1) * KA * GS, tile + 1, P, K, tid, dreg);
+        if (more) gv_write_d<T, AT, NW, FAST>(sdt + (buf ^ 1) * DBUF, tile + 1, P, K, tid, dreg);
     }
     if (active) {                                                 // partial sums of this workgroup: slab[wg][row][atom]
         float* dst = slab + (size_t)blockIdx.x * Bp * KA;
@@ -844,11 +1008,11 @@ template <> struct ColFrag<bf16_t> {
 };
 template <> struct ColFrag<float> {
     static __device__ __forceinline__ Mma<float>::Frag load(const float* img, int GS, int rb, int col0, int lane) {
-        Mma<float>::Frag f;
+        float f[8];
         const float* a = img + (rb + 8 * (lane >> 5)) * GS + col0 + (lane & 31);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f.v[j] = a[j * GS];
-        return f;
+        for (int j = 0; j < 8; ++j) f[j] = a[j * GS];
+        return Mma<float>::from8(f);
     }
 };
 
@@ -878,9 +1042,10 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
     constexpr int NKG = RS / 16;                                 // k-groups of 16 rows per wave
     constexpr int RPW = 16 / KS;                                 // accumulator registers each wave finishes
     static_assert(KS <= 16 && 16 % KS == 0, "row splits must divide the 16 accumulator registers");
+    constexpr int GD = GV_TW + DPAD, DPL = KA * GD, DBUF = DImg<T>::PLANES * DPL;   // D tile: planes of [KA][GD] bf16
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    E* sdt = reinterpret_cast<E*>(smem_raw);                     // [2][KA][GS]
-    E* simg = sdt + 2 * KA * GS;                                 // [NBLK][32][GS]  the g block of this tile
+    bf16_t* sdt = reinterpret_cast<bf16_t*>(smem_raw);           // [2][PLANES][KA][GD]
+    E* simg = reinterpret_cast<E*>(sdt + 2 * DBUF);              // [NBLK][32][GS]  the g block of this tile
     float* red = reinterpret_cast<float*>(simg + NBLK * 32 * GS);   // [NW][16][64]  grad_d row-split partials
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int t0 = tile_begin + blockIdx.x * tiles_per_wg;
@@ -897,18 +1062,18 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
     const int lrow = lane / LPR, lcol = (lane - lrow * LPR) * EPL;
 
     // tile-invariant B fragments of grad_d: codes (transposed, converted) of this wave's row split
-    Frag vfr[NKG];
+    typename M::Raw vfr[NKG];
 #pragma unroll
     for (int kg = 0; kg < NKG; ++kg) {
         const int r0 = ks * RS + 16 * kg;
         const int rr = (r0 < Bp) ? r0 : 0;                       // splits beyond the batch are skipped below
-        vfr[kg] = M::load8(vpt + (size_t)(ta * 32 + c) * vstride + rr + 8 * h);
+        vfr[kg] = M::load8_raw(vpt + (size_t)(ta * 32 + c) * vstride + rr + 8 * h);
     }
     // Retire these loads BEFORE the tile loop.  hipcc's waitcnt insertion is path-insensitive: if the fragments could
     // still be in flight at the loop header it guards every use inside the loop with a counted vmcnt that, in steady
     // state, drains the prefetched next-tile loads instead (vmcnt is in issue order) — the kernel loses all overlap.
 #pragma unroll
-    for (int kg = 0; kg < NKG; ++kg) M::touch(vfr[kg]);
+    for (int kg = 0; kg < NKG; ++kg) M::touch_raw(vfr[kg]);
 
     float dreg[DPT];
     u32x4 blk[RB][NLD];
@@ -939,7 +1104,7 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
         }
         lds_barrier();                                          // all images + D[buf] visible
         {                                                         // ---- grad_v: rows of this wave, all 64 pixels
-            const E* sdb = sdt + buf * KA * GS;
+            const bf16_t* sdb = sdt + buf * DBUF;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 if ((w * RB + rb) * 32 < Bp) {
@@ -949,7 +1114,7 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
                         const Frag a = M::load8(sg + c * GS + 16 * g3 + 8 * h);
 #pragma unroll
                         for (int at = 0; at < AT; ++at) {
-                            const Frag bfr = M::load8(sdb + (at * 32 + c) * GS + 16 * g3 + 8 * h);
+                            const Frag bfr = DImg<T>::load8(sdb + (at * 32 + c) * GD + 16 * g3 + 8 * h, DPL);
                             M::mma(accv[rb][at], a, bfr);
                         }
                     }
@@ -960,12 +1125,16 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
         f32x16 accd;
 #pragma unroll
         for (int r = 0; r < 16; ++r) accd[r] = 0.0f;
+        if constexpr (sizeof(T) == 4) {                          // fp32: keep the (loop-invariant) three-way split of the
+#pragma unroll                                                    // codes from being hoisted back into 12 registers each
+            for (int kg = 0; kg < NKG; ++kg) M::touch_raw(vfr[kg]);
+        }
         if (Bp == NBLK * 32) {                                    // full workgroup: no per-k-group conditions, so the
 #pragma unroll                                                    // column reads of several k-groups are in flight together
             for (int kg = 0; kg < NKG; ++kg) {
                 const int r0 = ks * RS + 16 * kg;
                 const Frag a = ColFrag<T>::load(simg + (size_t)(r0 >> 5) * 32 * GS, GS, r0 & 16, tp * 32, lane);
-                M::mma(accd, a, vfr[kg]);
+                M::mma(accd, a, M::expand(vfr[kg]));
             }
         } else {
 #pragma unroll
@@ -973,7 +1142,7 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
                 const int r0 = ks * RS + 16 * kg;
                 if (r0 < Bp) {                                    // wave-uniform
                     const Frag a = ColFrag<T>::load(simg + (size_t)(r0 >> 5) * 32 * GS, GS, r0 & 16, tp * 32, lane);
-                    M::mma(accd, a, vfr[kg]);
+                    M::mma(accd, a, M::expand(vfr[kg]));
                 }
             }
         }
@@ -1003,7 +1172,7 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
             }
         }
         if (KS == 1) lds_barrier();                             // image reads done before the next tile overwrites
-        if (more) gv_write_d<T, AT, NW, FAST>(sdt + (buf ^ 1) * KA * GS, tile + 1, P, K, tid, dreg);
+        if (more) gv_write_d<T, AT, NW, FAST>(sdt + (buf ^ 1) * DBUF, tile + 1, P, K, tid, dreg);
     }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -1088,7 +1257,7 @@ static int launch_synth_range(const void* x, const float* d, const float* vp, vo
     using E = typename Mma<T>::Elem;
     if (ntiles <= 0) return 0;
     const int Kp = round_up(K, 16);
-    const size_t lds = (size_t)SYNTH_TILE * (Kp + Mma<T>::PAD) * sizeof(E);
+    const size_t lds = (size_t)DImg<T>::PLANES * SYNTH_TILE * (Kp + DPAD) * sizeof(bf16_t);
     int rc = set_lds((const void*)synth_mfma_kernel<T, XACC, FAST>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((synth_mfma_kernel<T, XACC, FAST>), dim3(ntiles), dim3(256), lds, st, (const T*)x, d, vp, (T*)out,
@@ -1160,13 +1329,14 @@ static int launch_grad_d(const T* g, const float* vp, float* grad_d, int B, int 
 }
 
 // waves (= 32-row batch blocks) per grad_v workgroup: bounded by the 160 KiB of LDS holding one g image per wave
-template <typename T> struct GradVWaves { static constexpr int kMax = sizeof(T) == 2 ? 16 : 8; };
+// waves (= 32-row blocks) per grad_v workgroup, bounded by LDS: fp32 streams stage three planes of the D tile
+template <typename T, int AT> struct GradVWaves { static constexpr int kMax = sizeof(T) == 2 ? 16 : (AT <= 2 ? 8 : 4); };
 
 template <typename T, int AT>
 static size_t grad_v_lds_bytes(int nwaves) {
     using E = typename Mma<T>::Elem;
-    const size_t GS = GV_TW + Mma<T>::PAD;
-    return (2 * (size_t)AT * 32 * GS + (size_t)nwaves * 32 * GS) * sizeof(E);
+    const size_t GS = GV_TW + Mma<T>::PAD, GD = GV_TW + DPAD;
+    return 2 * (size_t)DImg<T>::PLANES * AT * 32 * GD * sizeof(bf16_t) + (size_t)nwaves * 32 * GS * sizeof(E);
 }
 
 template <typename T, int AT, int NW, bool FAST>
@@ -1185,11 +1355,13 @@ template <typename T, int AT, bool FAST>
 static int launch_grad_v_range(const T* g, const float* d, float* slab, int rows, int rows_p, int P, int K, int tile_begin,
                                int tile_end, int nwg, int tiles_per_wg, hipStream_t st) {
     if (nwg <= 0) return 0;
-    const int nwaves = rows_p / 32;                               // <= GradVWaves<T>::kMax
-    if constexpr (GradVWaves<T>::kMax >= 16) {
+    const int nwaves = rows_p / 32;                               // <= GradVWaves<T, AT>::kMax
+    if constexpr (GradVWaves<T, AT>::kMax >= 16) {
         if (nwaves > 8) return launch_grad_v_nw<T, AT, 16, FAST>(g, d, slab, rows, rows_p, P, K, tile_begin, tile_end, nwg, tiles_per_wg, st);
     }
-    if (nwaves > 4) return launch_grad_v_nw<T, AT, 8, FAST>(g, d, slab, rows, rows_p, P, K, tile_begin, tile_end, nwg, tiles_per_wg, st);
+    if constexpr (GradVWaves<T, AT>::kMax >= 8) {
+        if (nwaves > 4) return launch_grad_v_nw<T, AT, 8, FAST>(g, d, slab, rows, rows_p, P, K, tile_begin, tile_end, nwg, tiles_per_wg, st);
+    }
     return launch_grad_v_nw<T, AT, 4, FAST>(g, d, slab, rows, rows_p, P, K, tile_begin, tile_end, nwg, tiles_per_wg, st);
 }
 
@@ -1204,7 +1376,7 @@ static int launch_grad_v(const T* g, const float* d, float* grad_vb, int B, int 
     const int nwg_fast = nfast > 0 ? (nfast + tpw_fast - 1) / tpw_fast : 0;
     const int tpw_slow = nslow > 0 ? (nslow + kNumCU - 1) / kNumCU : 1;
     const int nwg_slow = nslow > 0 ? (nslow + tpw_slow - 1) / tpw_slow : 0;
-    const int chunk = GradVWaves<T>::kMax * 32;
+    const int chunk = GradVWaves<T, AT>::kMax * 32;
     for (int r0 = 0; r0 < Bp; r0 += chunk) {
         const int rows_p = imin(Bp - r0, chunk), rows = imin(B - r0, rows_p);
         const T* gc = g + (size_t)r0 * P;
@@ -1229,8 +1401,9 @@ template <typename T, int AT> struct FusedCfg {
 template <typename T, int AT, int NW, int RB>
 static size_t grad_fused_lds_bytes() {
     using E = typename Mma<T>::Elem;
-    const size_t GS = GV_TW + Mma<T>::PAD;
-    return (2 * (size_t)AT * 32 * GS + (size_t)NW * RB * 32 * GS) * sizeof(E) + (size_t)NW * 16 * 64 * sizeof(float);
+    const size_t GS = GV_TW + Mma<T>::PAD, GD = GV_TW + DPAD;
+    return 2 * (size_t)DImg<T>::PLANES * AT * 32 * GD * sizeof(bf16_t) + (size_t)NW * RB * 32 * GS * sizeof(E) +
+           (size_t)NW * 16 * 64 * sizeof(float);
 }
 
 template <typename T, int AT, int NW, int RB, bool FAST>
@@ -1306,7 +1479,13 @@ static int launch_grad_cfg(const T* g, const float* d, const float* vp, float* g
     float* slab = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + (((size_t)KA * Bp * sizeof(float) + 255) / 256) * 256);
     int rc = 0;
     if constexpr (FusedCfg<T, AT>::kMaxRows > 0) {                 // learning step: both outputs from ONE pass over g
-        if (grad_d != nullptr && grad_vb != nullptr)
+        // ... while the batch fits one fused launch (fp32) or two (bf16).  Every further row chunk has to ACCUMULATE into
+        // grad_d, i.e. put a dependent global load behind every store, which drains the prefetched tile on every iteration
+        // (vmcnt retires in order).  Measured, fused chunks vs the two single-output kernels: fp32 512 rows K=50 250 vs
+        // 242 us; bf16 1024 rows K=50 (2 chunks) 146 vs 198 us; bf16 1024 rows K=100 (4 chunks) 345 vs 295 us.
+        constexpr int kRows = FusedCfg<T, AT>::kMaxRows;
+        const bool fused = sizeof(T) == 2 ? (Bp <= 2 * kRows) : (Bp <= kRows);
+        if (grad_d != nullptr && grad_vb != nullptr && fused)
             return launch_grad_fused<T, AT>(g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, slab, st);
     }
     if (grad_d != nullptr) rc = launch_grad_d<T, PXT, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, st);
@@ -1321,7 +1500,7 @@ static int launch_grad(const void* g, const float* d, const float* vp, float* gr
     const int at = grad_at(K);
     if (at == 1) return launch_grad_cfg<T, 4, 1>((const T*)g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, st);
     if (at == 2) return launch_grad_cfg<T, 2, 2>((const T*)g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, st);
-    return launch_grad_cfg<T, 1, 4>((const T*)g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, st);
+    return launch_grad_cfg<T, 2, 4>((const T*)g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, st);
 }
 
 extern "C" int adil_grad(const void* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P,
@@ -1343,7 +1522,7 @@ static int launch_zstep_range(float* z, float* m, float* sq, const float* d, con
                               hipStream_t st) {
     if (ntiles <= 0) return 0;
     const int Kp = round_up(K, 16);
-    const size_t lds = (size_t)SYNTH_TILE * (Kp + Mma<float>::PAD) * sizeof(float);
+    const size_t lds = (size_t)DImg<float>::PLANES * SYNTH_TILE * (Kp + DPAD) * sizeof(bf16_t);
     int rc = set_lds((const void*)zstep_mfma_kernel<FAST>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((zstep_mfma_kernel<FAST>), dim3(ntiles), dim3(256), lds, st, z, m, sq, d, vp, B, P, K, Kp, hy, lo, hi,
@@ -1358,7 +1537,8 @@ extern "C" int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, co
     ADIL_ENTER();
     if (!z || !m || !s || !dpinv_t || !gvp || B <= 0 || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     AdamWHyper hy{decay, b1, b2, eps, step_size, bc2_sqrt};
-    const bool vec = (P % 4 == 0) && ((((uintptr_t)z | (uintptr_t)m | (uintptr_t)s) % 16) == 0);
+    const bool vec = (P % 4 == 0) && ((((uintptr_t)z | (uintptr_t)m | (uintptr_t)s | (uintptr_t)dpinv_t) % 16) == 0) &&
+                     (P <= (1 << 23));                           // 32-row blocks addressable with 32-bit byte offsets
     const int ntiles = (P + SYNTH_TILE - 1) / SYNTH_TILE;
     const int nfast = vec ? P / SYNTH_TILE : 0;
     int rc = launch_zstep_range<true>(z, m, s, dpinv_t, gvp, B, P, K, hy, lo, hi, max_abs_delta, 0, nfast, (hipStream_t)stream);

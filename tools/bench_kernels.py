@@ -22,6 +22,7 @@ g0 = torch.Generator().manual_seed(0)
 d = (-1 + 2 * torch.rand(3, S, S, K, generator=g0)).to(dev)
 v = (torch.randn(B, K, generator=g0) * 0.01).to(dev)
 vp = ops.pack_codes(v, None, B)
+print(f"B={B} K={K} P={P}")
 for dt, s in ((torch.bfloat16, 2), (torch.float32, 4)):
     x = torch.rand(B, 3, S, S, generator=g0).to(dev).to(dt)
     g = torch.randn(B, 3, S, S, generator=g0).to(dev).to(dt)
