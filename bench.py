@@ -54,6 +54,8 @@ def parse_args():
                    help="zero-pad the first conv's 3 input channels to this width (0 = off); see zoo.ChannelPaddedConv")
     p.add_argument("--cache-labels", type=int, default=0,
                    help="1: compute the (constant) clean pseudo-labels once instead of every step (reference quirk Q4)")
+    p.add_argument("--fp8-synth", type=int, default=0,
+                   help="1: the D.V contraction of the synthesis on fp8 (e4m3) MFMAs (BASELINE.json configs[4]); learn mode")
     p.add_argument("--cpu-baseline", type=int, default=1)
     p.add_argument("--cpu-batch", type=int, default=32, help="images of the config-2-shape CPU sample")
     p.add_argument("--cpu-steps", type=int, default=1)
@@ -283,7 +285,8 @@ def main():
             solver.iterate()                                  # no host sync: the stop test is left to the caller
             return None, None
     else:
-        learner = engine.DictionaryLearner(d, v, eps, 0.01, args.loss, False, 50.0, reducer=reducer)
+        learner = engine.DictionaryLearner(d, v, eps, 0.01, args.loss, False, 50.0, reducer=reducer,
+                                           fp8_synth=bool(args.fp8_synth))
         index = torch.arange(B, device=dev)
         labels = engine.predict(model, x) if args.cache_labels else None
 
@@ -339,7 +342,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": (f"ADiL learn_dictionary_a step vs {args.model}, {B} images/GPU, {K} atoms, "
-                                f"{S}x{S}, {args.dtype} image streams + fp32 D/V master, loss={args.loss}, "
+                                f"{S}x{S}, {args.dtype} image streams + fp32 D/V master"
+                                f"{', fp8 (e4m3) operands in the synthesis contraction' if args.fp8_synth else ''}, loss={args.loss}, "
                                 f"{'cached' if args.cache_labels else 'recomputed'} pseudo-labels (2 fwd + 1 bwd)")
                    if args.mode == "learn" else
                    (f"ADiL forward_supervised_DDrague iteration (the attack(x, y) path of transfer evaluation) vs "

@@ -29,6 +29,7 @@ template <typename T> struct Mma;
 // accumulation, and an error per product of the size of one fp32 rounding (bf16 x bf16 products are exact in fp32).
 // Small terms are issued first so that they are not absorbed by a large partial sum.
 template <> struct Mma<float> {
+    static constexpr bool SCALED = false;
     struct Frag { bf16x8 h, m, l; };
     typedef float Elem;                         // element type of operands staged in LDS / workspace
     static constexpr int PAD = 4;               // LDS row padding (elements): (stride/4) odd -> conflict-free b128
@@ -89,6 +90,7 @@ template <> struct Mma<float> {
 };
 
 template <> struct Mma<bf16_t> {
+    static constexpr bool SCALED = false;
     typedef bf16x8 Frag;
     typedef bf16_t Elem;
     static constexpr int PAD = 8;               // (stride*2/16) odd
@@ -114,6 +116,33 @@ template <> struct Mma<bf16_t> {
     static __device__ __forceinline__ void touch_raw(Raw& r) { touch(r); }
 };
 
+// fp8 (OCP e4m3 on gfx950) operands for the D.V contraction of the synthesis (BASELINE.json configs[4]): both operands
+// are SCALED into the e4m3 range before conversion (codes by vscale = 384 / max|v|, the dictionary by dscale = 256:
+// |D| <= 1 is an invariant of update_d, adil.py:33-35) and the fp32 accumulator is scaled back by 1 / (vscale dscale).
+// Same fragment geometry as bf16 (lane (r, h) supplies reduction indices 16 g + 8 h + j), 8 bytes per fragment,
+// v_mfma_f32_32x32x16_fp8_fp8: twice the bf16 MFMA rate, half the LDS bytes per D-slice read.
+struct fp8_t { unsigned char bits; };
+struct OpScale { float v, d, o; };              // code scale, dictionary scale, output scale 1 / (v d)
+__device__ __forceinline__ float fp8_range(float x) { return fminf(fmaxf(x, -448.0f), 448.0f); }   // e4m3 max normal
+template <> struct Mma<fp8_t> {
+    typedef long Frag;
+    static constexpr bool SCALED = true;
+    static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned pack4(float a, float b, float c, float d) {
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_range(a), fp8_range(b), w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_range(c), fp8_range(d), w, true);
+        return (unsigned)w;
+    }
+    static __device__ __forceinline__ Frag from8(const float (&f)[8]) {       // values already scaled
+        const unsigned lo = pack4(f[0], f[1], f[2], f[3]), hi = pack4(f[4], f[5], f[6], f[7]);
+        return (long)(((unsigned long)hi << 32) | (unsigned long)lo);
+    }
+    static __device__ __forceinline__ void touch(Frag& f) { asm volatile("" : "+v"(f)); }
+};
+
 // ---- the dictionary operand staged in LDS ------------------------------------------------------------------- //
 // Always bf16 elements, row stride n + DPAD.  bf16 streams keep one plane (D rounded to bf16); fp32 streams keep the
 // THREE planes h, m, l of Mma<float>'s split, written once per workgroup when the slice / tile is staged: the shared
@@ -122,6 +151,7 @@ template <> struct Mma<bf16_t> {
 #define DPAD 8
 template <typename T> struct DImg;
 template <> struct DImg<bf16_t> {
+    typedef bf16_t Elem;
     static constexpr int PLANES = 1;
     static __device__ __forceinline__ void put(bf16_t* img, int off, int plane, float v) { (void)plane; img[off] = f32_to_bf16(v); }
     static __device__ __forceinline__ void put2(bf16_t* img, int off, int plane, const float (&f)[2]) {
@@ -138,6 +168,7 @@ template <> struct DImg<bf16_t> {
     }
 };
 template <> struct DImg<float> {
+    typedef bf16_t Elem;
     static constexpr int PLANES = 3;
     static __device__ __forceinline__ void put2(bf16_t* img, int off, int plane, const float (&f)[2]) {
         unsigned h, m, l;
@@ -167,6 +198,27 @@ template <> struct DImg<float> {
         r.m = *reinterpret_cast<const bf16x8*>(p + plane);
         r.l = *reinterpret_cast<const bf16x8*>(p + 2 * plane);
         return r;
+    }
+};
+
+template <> struct DImg<fp8_t> {                 // one byte per element, values pre-scaled by OpScale::d
+    typedef unsigned char Elem;                  // row stride Kp + DPAD bytes: an odd number of 8-byte slots (Kp % 16 == 0)
+    static constexpr int PLANES = 1;
+    static __device__ __forceinline__ void put(unsigned char* img, int off, int plane, float v) {
+        (void)plane;
+        img[off] = (unsigned char)(Mma<fp8_t>::pack4(v, 0.0f, 0.0f, 0.0f) & 0xffu);
+    }
+    static __device__ __forceinline__ void put2(unsigned char* img, int off, int plane, const float (&f)[2]) {
+        (void)plane;
+        *reinterpret_cast<unsigned short*>(img + off) = (unsigned short)(Mma<fp8_t>::pack4(f[0], f[1], 0.0f, 0.0f) & 0xffffu);
+    }
+    static __device__ __forceinline__ void put4(unsigned char* img, int off, int plane, const float (&f)[4]) {
+        (void)plane;
+        *reinterpret_cast<unsigned*>(img + off) = Mma<fp8_t>::pack4(f[0], f[1], f[2], f[3]);
+    }
+    static __device__ __forceinline__ long load8(const unsigned char* p, int plane) {
+        (void)plane;
+        return *reinterpret_cast<const long*>(p);
     }
 };
 
@@ -302,9 +354,13 @@ __device__ __forceinline__ typename Mma<T>::Frag load_frag8(const T* rowp, int p
 
 // 8 consecutive fp32 values (16-B aligned, e.g. a row of the packed codes) as an MFMA fragment
 template <typename T>
-__device__ __forceinline__ typename Mma<T>::Frag frag_from_f32x8(const float* p) {
+__device__ __forceinline__ typename Mma<T>::Frag frag_from_f32x8(const float* p, float scale = 1.0f) {
     const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
-    const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if constexpr (Mma<T>::SCALED) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] *= scale;
+    }
     return Mma<T>::from8(f);
 }
 
@@ -346,16 +402,17 @@ __device__ __forceinline__ int c_row(int reg, int h) { return (reg & 3) + 8 * (r
 // =========================================================================================================== //
 #define SYNTH_TILE 128
 
-template <typename T, bool XACC, bool FAST>
+template <typename T, typename O, bool XACC, bool FAST>
 __device__ __forceinline__ void synth_sweep(const T* __restrict__ x, const float* __restrict__ vp, T* __restrict__ out,
-                                            const bf16_t* sd, int B, int P, int Kp, int Ks, int p0,
-                                            float delta_clamp, int pixel_clamp, int w, int c, int h) {
-    using M = Mma<T>;
+                                            const typename DImg<O>::Elem* sd, int B, int P, int Kp, int Ks, int p0,
+                                            float delta_clamp, int pixel_clamp, int w, int c, int h, OpScale sc) {
+    using M = Mma<O>;
     using Frag = typename M::Frag;
     const int plane = SYNTH_TILE * Ks;
     const int NG = Kp >> 4;
     const int nbb = (B + 31) >> 5;
     const int px = p0 + 4 * c;
+    const float xs = sc.v * sc.d;                 // scaled operands: x rides in the accumulator in product units
     for (int bb = w; bb < nbb; bb += 4) {
         const int b0 = bb << 5;
         f32x16 acc[4];
@@ -367,16 +424,16 @@ __device__ __forceinline__ void synth_sweep(const T* __restrict__ x, const float
                 load_px<T, 4, FAST>(x + (size_t)(row < B ? row : B - 1) * P, px, P, xv);   // rows >= B are never stored
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t][reg] = xv[t];
+            for (int t = 0; t < 4; ++t) acc[t][reg] = M::SCALED ? xv[t] * xs : xv[t];
         }
         const float* arow = vp + (size_t)(b0 + c) * Kp + 8 * h;
-        Frag a = frag_from_f32x8<T>(arow);
+        Frag a = frag_from_f32x8<O>(arow, sc.v);
         for (int g = 0; g < NG; ++g) {
             const int gn = (g + 1 < NG) ? g + 1 : g;
-            const Frag an = frag_from_f32x8<T>(arow + 16 * gn);                            // prefetch the next k-group
+            const Frag an = frag_from_f32x8<O>(arow + 16 * gn, sc.v);                      // prefetch the next k-group
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const Frag bf = DImg<T>::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h, plane);
+                const Frag bf = DImg<O>::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h, plane);
                 M::mma(acc[t], a, bf);
             }
             a = an;
@@ -386,7 +443,7 @@ __device__ __forceinline__ void synth_sweep(const T* __restrict__ x, const float
             const int row = b0 + c_row(reg, h);
             float r[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) r[t] = acc[t][reg];
+            for (int t = 0; t < 4; ++t) r[t] = M::SCALED ? acc[t][reg] * sc.o : acc[t][reg];
             if (!XACC) {
                 if (delta_clamp >= 0.0f) {
 #pragma unroll
@@ -408,16 +465,16 @@ __device__ __forceinline__ void synth_sweep(const T* __restrict__ x, const float
     }
 }
 
-template <typename T, bool XACC, bool PIXCLAMP>
+template <typename T, bool XACC, bool PIXCLAMP, bool SCALED>
 __device__ __forceinline__ void synth_store_buf(const f32x16 (&acc)[4], buf_rsrc rx, buf_rsrc ro, int voff, unsigned rowb,
-                                                float delta_clamp) {
+                                                float delta_clamp, float oscale) {
     using BP = BufPx<T>;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int soff = (int)((unsigned)c_row(reg, 0) * rowb);
         float r[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) r[t] = acc[t][reg];
+        for (int t = 0; t < 4; ++t) r[t] = SCALED ? acc[t][reg] * oscale : acc[t][reg];
         if (!XACC) {
             if (delta_clamp >= 0.0f) {
 #pragma unroll
@@ -440,12 +497,12 @@ __device__ __forceinline__ void synth_store_buf(const f32x16 (&acc)[4], buf_rsrc
 // SYNTH_HOIST k-groups loaded up front, BEFORE the 16 x loads, so that per batch block a wave pays one L2 round trip
 // for its codes (hidden under the HBM latency of x) instead of one per k-group in the MFMA loop.
 #define SYNTH_HOIST 4
-template <typename T, bool XACC>
+template <typename T, typename O, bool XACC>
 __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const float* __restrict__ vp,
-                                                T* __restrict__ out, const bf16_t* sd, int B, int P,
+                                                T* __restrict__ out, const typename DImg<O>::Elem* sd, int B, int P,
                                                 int Kp, int Ks, int p0, float delta_clamp, int pixel_clamp, int w, int c,
-                                                int h) {
-    using M = Mma<T>;
+                                                int h, OpScale sc) {
+    using M = Mma<O>;
     using Frag = typename M::Frag;
     using BP = BufPx<T>;
     const int plane = SYNTH_TILE * Ks;
@@ -481,8 +538,12 @@ __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const f
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 asm volatile("" : "+v"(araw[g][u].x), "+v"(araw[g][u].y), "+v"(araw[g][u].z), "+v"(araw[g][u].w));
-            const float f[8] = {araw[g][0].x, araw[g][0].y, araw[g][0].z, araw[g][0].w,
-                                araw[g][1].x, araw[g][1].y, araw[g][1].z, araw[g][1].w};
+            float f[8] = {araw[g][0].x, araw[g][0].y, araw[g][0].z, araw[g][0].w,
+                          araw[g][1].x, araw[g][1].y, araw[g][1].z, araw[g][1].w};
+            if constexpr (M::SCALED) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] *= sc.v;
+            }
             a[g] = M::from8(f);
         }
         f32x16 acc[4];
@@ -491,33 +552,34 @@ __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const f
             float xv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (XACC) BP::unpack(xr[reg], xv);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t][reg] = xv[t];
+            for (int t = 0; t < 4; ++t) acc[t][reg] = M::SCALED ? xv[t] * (sc.v * sc.d) : xv[t];
         }
 #pragma unroll
         for (int g = 0; g < SYNTH_HOIST; ++g) {
             if (g < NG) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) M::mma(acc[t], a[g], DImg<T>::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h, plane));
+                for (int t = 0; t < 4; ++t) M::mma(acc[t], a[g], DImg<O>::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h, plane));
             }
         }
         for (int g = SYNTH_HOIST; g < NG; ++g) {                                         // K > 64
-            const Frag ag = frag_from_f32x8<T>(arow + 16 * g);
+            const Frag ag = frag_from_f32x8<O>(arow + 16 * g, sc.v);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) M::mma(acc[t], ag, DImg<T>::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h, plane));
+            for (int t = 0; t < 4; ++t) M::mma(acc[t], ag, DImg<O>::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h, plane));
         }
         if (pixel_clamp)                                                                  // uniform: one branch per block
-            synth_store_buf<T, XACC, true>(acc, rx, ro, voff, rowb, delta_clamp);
+            synth_store_buf<T, XACC, true, M::SCALED>(acc, rx, ro, voff, rowb, delta_clamp, sc.o);
         else
-            synth_store_buf<T, XACC, false>(acc, rx, ro, voff, rowb, delta_clamp);
+            synth_store_buf<T, XACC, false, M::SCALED>(acc, rx, ro, voff, rowb, delta_clamp, sc.o);
     }
 }
 
 // The 128-pixel slice of the dictionary operand (D for synth, D_dagger^T for the z-step) -> LDS planes of DImg<T>,
 // tile-major rows (pixel r at row (r&3)*32 + (r>>2)), padded atoms zeroed.  256 threads.
 template <typename T, bool FAST>
-__device__ __forceinline__ void fill_dict_slice(const float* __restrict__ d, bf16_t* sd, int p0, int P, int K, int Kp,
-                                                int Ks, int tid) {
+__device__ __forceinline__ void fill_dict_slice(const float* __restrict__ d, typename DImg<T>::Elem* sd, int p0, int P, int K,
+                                                int Kp, int Ks, int tid, float dscale = 1.0f) {
     using DI = DImg<T>;
+    using M = Mma<T>;
     const int plane = SYNTH_TILE * Ks;
     if constexpr (FAST) {
         // D slice -> LDS.  The slice (128 pixels x K atoms) is one contiguous, 16-byte aligned run of 32*K float4:
@@ -541,7 +603,11 @@ __device__ __forceinline__ void fill_dict_slice(const float* __restrict__ d, bf1
                     const int i = 4 * q;
                     int r = (int)(((float)i + 0.5f) * rk);           // i / K, exact: |error| << 0.5 / K for i < 2^14
                     int k = i - r * K;
-                    const float e4[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
+                    float e4[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
+                    if constexpr (M::SCALED) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) e4[e] *= dscale;
+                    }
                     if ((K & 3) == 0) {                              // uniform: the quad stays inside one row
                         DI::put4(sd, ((r & 3) * 32 + (r >> 2)) * Ks + k, plane, e4);
                     } else if ((K & 1) == 0) {                       // pairs stay inside one row
@@ -578,33 +644,33 @@ __device__ __forceinline__ void fill_dict_slice(const float* __restrict__ d, bf1
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + 256 * u;
                 const int r = i / Kp, k = i - r * Kp;
-                DI::put(sd, ((r & 3) * 32 + (r >> 2)) * Ks + k, plane, val[u]);
+                DI::put(sd, ((r & 3) * 32 + (r >> 2)) * Ks + k, plane, M::SCALED ? val[u] * dscale : val[u]);
             }
         }
     }
 }
 
-template <typename T, bool XACC, bool FAST>
+template <typename T, typename O, bool XACC, bool FAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void synth_mfma_kernel(const T* __restrict__ x, const float* __restrict__ d,
                                                          const float* __restrict__ vp, T* __restrict__ out, int B,
                                                          int P, int K, int Kp, float delta_clamp, int pixel_clamp,
-                                                         int tile0) {
-    using DI = DImg<T>;
+                                                         int tile0, OpScale sc) {
+    using DE = typename DImg<O>::Elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16_t* sd = reinterpret_cast<bf16_t*>(smem_raw);            // [PLANES][128][Ks] bf16
+    DE* sd = reinterpret_cast<DE*>(smem_raw);                    // [PLANES][128][Ks] bf16 (fp8: bytes)
     const int Ks = Kp + DPAD;
     const int plane = SYNTH_TILE * Ks;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     // consecutive tiles go to consecutive workgroups, i.e. round-robin over the 8 XCDs: for this pure stream that is
     // 8 % faster than giving each XCD one contiguous range of tiles (measured)
     const int p0 = (tile0 + blockIdx.x) * SYNTH_TILE;
-    fill_dict_slice<T, FAST>(d, sd, p0, P, K, Kp, Ks, tid);
+    fill_dict_slice<O, FAST>(d, sd, p0, P, K, Kp, Ks, tid, sc.d);
     __syncthreads();
     if constexpr (FAST)
-        synth_sweep_buf<T, XACC>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp,
-                                 __builtin_amdgcn_readfirstlane(w), c, h);
+        synth_sweep_buf<T, O, XACC>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp,
+                                    __builtin_amdgcn_readfirstlane(w), c, h, sc);
     else
-        synth_sweep<T, XACC, FAST>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp, w, c, h);
+        synth_sweep<T, O, XACC, FAST>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp, w, c, h, sc);
 }
 
 // =========================================================================================================== //
@@ -1251,41 +1317,60 @@ extern "C" size_t adil_grad_workspace_bytes(int B, int P, int K) {
     return ((vpt + 255) / 256) * 256 + slab;
 }
 
-template <typename T, bool XACC, bool FAST>
+template <typename T, typename O, bool XACC, bool FAST>
 static int launch_synth_range(const void* x, const float* d, const float* vp, void* out, int B, int P, int K,
-                              float delta_clamp, int pixel_clamp, int tile0, int ntiles, hipStream_t st) {
-    using E = typename Mma<T>::Elem;
+                              float delta_clamp, int pixel_clamp, int tile0, int ntiles, OpScale sc, hipStream_t st) {
     if (ntiles <= 0) return 0;
     const int Kp = round_up(K, 16);
-    const size_t lds = (size_t)DImg<T>::PLANES * SYNTH_TILE * (Kp + DPAD) * sizeof(bf16_t);
-    int rc = set_lds((const void*)synth_mfma_kernel<T, XACC, FAST>, lds);
+    const size_t lds = (size_t)DImg<O>::PLANES * SYNTH_TILE * (Kp + DPAD) * sizeof(typename DImg<O>::Elem);
+    int rc = set_lds((const void*)synth_mfma_kernel<T, O, XACC, FAST>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((synth_mfma_kernel<T, XACC, FAST>), dim3(ntiles), dim3(256), lds, st, (const T*)x, d, vp, (T*)out,
-                       B, P, K, Kp, delta_clamp, pixel_clamp, tile0);
+    hipLaunchKernelGGL((synth_mfma_kernel<T, O, XACC, FAST>), dim3(ntiles), dim3(256), lds, st, (const T*)x, d, vp, (T*)out,
+                       B, P, K, Kp, delta_clamp, pixel_clamp, tile0, sc);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
 
 // full (interior, vector-aligned) tiles go through the FAST kernel, the ragged tail / unaligned rows through the
 // element-wise one
-template <typename T, bool XACC>
+template <typename T, typename O, bool XACC>
 static int launch_synth_x(const void* x, const float* d, const float* vp, void* out, int B, int P, int K,
-                          float delta_clamp, int pixel_clamp, hipStream_t st) {
+                          float delta_clamp, int pixel_clamp, OpScale sc, hipStream_t st) {
     // FAST = vector-aligned rows, and a 32-row block addressable with 32-bit byte offsets (buffer instructions)
     const bool vec = (P % 4 == 0) && (((uintptr_t)out | (uintptr_t)x | (uintptr_t)d) % 16 == 0) && (P <= (1 << 23));
     const int ntiles = (P + SYNTH_TILE - 1) / SYNTH_TILE;
     const int nfast = vec ? P / SYNTH_TILE : 0;
-    int rc = launch_synth_range<T, XACC, true>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, 0, nfast, st);
+    int rc = launch_synth_range<T, O, XACC, true>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, 0, nfast, sc, st);
     if (rc) return rc;
-    return launch_synth_range<T, XACC, false>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, nfast, ntiles - nfast, st);
+    return launch_synth_range<T, O, XACC, false>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, nfast, ntiles - nfast, sc, st);
 }
 
 template <typename T>
 static int launch_synth(const void* x, const float* d, const float* vp, void* out, int B, int P, int K,
                         float delta_clamp, int pixel_clamp, hipStream_t st) {
     const bool xacc = (x != nullptr) && (delta_clamp < 0.0f);
-    if (xacc) return launch_synth_x<T, true>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, st);
-    return launch_synth_x<T, false>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, st);
+    const OpScale one{1.0f, 1.0f, 1.0f};
+    if (xacc) return launch_synth_x<T, T, true>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, one, st);
+    return launch_synth_x<T, T, false>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, one, st);
+}
+
+extern "C" int adil_synth_fp8(const void* x, const float* d, const float* vp, void* out, int B, int P, int K, int dtype,
+                              float v_absmax, float delta_clamp, int pixel_clamp, void* stream) {
+    ADIL_ENTER();
+    if (!d || !vp || !out || B <= 0 || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS || !(v_absmax > 0.0f)) return ADIL_EINVAL;
+    OpScale sc;
+    sc.v = 384.0f / v_absmax;                    // codes: |v| <= v_absmax  ->  |v sc.v| <= 384 < 448 (e4m3 max normal)
+    sc.d = 256.0f;                               // dictionary: |D| <= 1 (update_d clamps it, adil.py:33-35)
+    sc.o = 1.0f / (sc.v * sc.d);
+    hipStream_t st = (hipStream_t)stream;
+    const bool xacc = (x != nullptr) && (delta_clamp < 0.0f);    // x rides in the accumulator, pre-multiplied by vscale*dscale
+    if (dtype == ADIL_F32)
+        return xacc ? launch_synth_x<float, fp8_t, true>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, sc, st)
+                    : launch_synth_x<float, fp8_t, false>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, sc, st);
+    if (dtype == ADIL_BF16)
+        return xacc ? launch_synth_x<bf16_t, fp8_t, true>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, sc, st)
+                    : launch_synth_x<bf16_t, fp8_t, false>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, sc, st);
+    return ADIL_EINVAL;
 }
 
 extern "C" int adil_synth(const void* x, const float* d, const float* vp, void* out, int B, int P, int K, int dtype,

@@ -77,7 +77,7 @@ class DictionaryLearner:
 
     def __init__(self, d: Tensor, v: Tensor, eps: float, step_size: float = 0.01, loss: str = "ce",
                  targeted: bool = False, kappa: float = 50.0, lr_d: Optional[float] = None,
-                 lr_v: Optional[float] = None, reducer: Optional[DictGradReducer] = None):
+                 lr_v: Optional[float] = None, reducer: Optional[DictGradReducer] = None, fp8_synth: bool = False):
         self.d = ops._dev(d, "d", torch.float32)
         self.v = ops._dev(v, "v", torch.float32)
         self.eps, self.loss, self.kappa = float(eps), loss, float(kappa)
@@ -89,6 +89,9 @@ class DictionaryLearner:
         self.pos = torch.full((v.shape[0],), -1, dtype=torch.int32, device=v.device)
         self.grad_d = torch.empty_like(d)
         self.reducer = reducer
+        # configs[4]: the D.V contraction of the synthesis on fp8 MFMAs.  Legal here because every row of v lives in
+        # the l1 ball of radius eps after update_v (so |v| <= eps bounds the code scale) and |d| <= 1 after update_d.
+        self.fp8_absmax = float(eps) if fp8_synth else None
 
     # -- pieces ------------------------------------------------------------- #
     def forward_backward(self, model, x: Tensor, index: Tensor, labels: Tensor, want_d: bool, want_v: bool):
@@ -97,7 +100,7 @@ class DictionaryLearner:
             return self._empty_batch(x, want_d)
         # the gather of the batch's code rows also records their batch slots in `pos` (consumed + reset by update_v)
         vp = ops.pack_codes(self.v, index, b, pos=self.pos if want_v else None)
-        xt = ops.synth(_flat_images(x), self.d, vp, b)                                  # K1
+        xt = ops.synth(_flat_images(x), self.d, vp, b, fp8_absmax=self.fp8_absmax)      # K1
         out, ls, g = input_gradient(model, xt, labels, self.loss, self.coeff, self.kappa, "sum")
         fooled = (out.argmax(dim=-1) != labels).sum()                                    # adil.py:177
         gd, gvb = ops.grad(g, self.d, vp, b, want_d=want_d, want_v=want_v,                # K2 + K3, one pass over g

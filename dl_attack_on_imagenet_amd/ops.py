@@ -143,8 +143,11 @@ def gather_images(src: Tensor, index: Optional[Tensor], out: Optional[Tensor] = 
 
 
 def synth(x: Optional[Tensor], d: Tensor, vp: Tensor, batch: int, *, out: Optional[Tensor] = None,
-          out_shape=None, out_dtype=None, delta_clamp: float = -1.0, pixel_clamp: bool = False) -> Tensor:
-    """out = x + vp D^T with optional +-delta_clamp on the perturbation and [0,1] pixel clamp."""
+          out_shape=None, out_dtype=None, delta_clamp: float = -1.0, pixel_clamp: bool = False,
+          fp8_absmax: Optional[float] = None) -> Tensor:
+    """out = x + vp D^T with optional +-delta_clamp on the perturbation and [0,1] pixel clamp.
+    fp8_absmax: contract with fp8 (e4m3) operands instead (adil_synth_fp8); the value is a bound on |vp| (the l1 radius
+    eps for projected codes) and |d| <= 1 is assumed (the invariant update_d maintains)."""
     lib = _lib.load()
     _dev(d, "d", torch.float32)
     _dev(vp, "vp", torch.float32)
@@ -159,6 +162,13 @@ def synth(x: Optional[Tensor], d: Tensor, vp: Tensor, batch: int, *, out: Option
     _dev(out, "out", out_dtype)
     if out.numel() != batch * p or vp.shape != (_round_up(batch, 32), _round_up(k, 16)):
         raise ValueError("synth: operand shapes do not match (B, P, K)")
+    if fp8_absmax is not None:
+        if not fp8_absmax > 0:
+            raise ValueError("fp8_absmax must be a positive bound on |vp|")
+        _lib.check(lib.adil_synth_fp8(_ptr(x), _ptr(d), _ptr(vp), _ptr(out), batch, p, k, stream_dtype_code(out.dtype),
+                                      float(fp8_absmax), float(delta_clamp), int(bool(pixel_clamp)), _stream()),
+                   "adil_synth_fp8")
+        return out
     _lib.check(lib.adil_synth(_ptr(x), _ptr(d), _ptr(vp), _ptr(out), batch, p, k, stream_dtype_code(out.dtype),
                               float(delta_clamp), int(bool(pixel_clamp)), _stream()), "adil_synth")
     return out

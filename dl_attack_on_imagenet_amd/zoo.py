@@ -219,9 +219,21 @@ class VisionTransformer(nn.Module):
         self.encoder = _Encoder((image_size // patch) ** 2 + 1, layers, heads, dim, mlp_dim)
         self.heads = nn.Sequential(OrderedDict([('head', nn.Linear(dim, num_classes))]))
 
+    def _patch_embed(self, x):
+        """conv_proj (kernel = stride = patch) as the GEMM it is: non-overlapping patches unfolded to rows, times the
+        (dim, 3*patch*patch) view of the convolution weight.  Same parameters, same function; but forward and the INPUT
+        gradient the attack needs are then plain library GEMMs, where the convolution's backward-data (3 output channels,
+        16x16 / stride 16) sends MIOpen into a run-time kernel search + compilation: measured 72 s for the first backward
+        at 256 images and > 120 s at 512 on a fresh MI355X box, which is what read as a "hang" in round 1."""
+        n, c, hh, ww = x.shape
+        p = self.patch
+        gh, gw = hh // p, ww // p
+        rows = x.reshape(n, c, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(n, gh * gw, c * p * p)
+        return F.linear(rows, self.conv_proj.weight.reshape(self.dim, c * p * p), self.conv_proj.bias)
+
     def forward(self, x):
         n = x.shape[0]
-        x = self.conv_proj(x).reshape(n, self.dim, -1).permute(0, 2, 1)
+        x = self._patch_embed(x)
         x = torch.cat([self.class_token.expand(n, -1, -1), x], dim=1)
         return self.heads(self.encoder(x)[:, 0])
 
@@ -805,6 +817,6 @@ def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights:
     model = model.to(device=device, dtype=dtype)
     if channels_last:
         model = model.to(memory_format=torch.channels_last)
-    if pad_input_channels and not stem_fused:
+    if pad_input_channels and not stem_fused and not isinstance(net, VisionTransformer):   # ViT: patch embedding is a GEMM
         pad_first_conv_(net, pad_input_channels)
     return model

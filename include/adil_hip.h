@@ -39,7 +39,8 @@ extern "C" {
 #define ADIL_EWORKSPACE (-2) /* workspace too small */
 
 /* ABI version of this header; bumped on any signature change.  2: frozen-classifier entry points.  3: batch-slot table
- * written by adil_pack_codes and consumed + reset by adil_adamw_l1ball, adil_gather_images, adil_spd_inverse. */
+ * written by adil_pack_codes and consumed + reset by adil_adamw_l1ball, adil_gather_images, adil_spd_inverse,
+ * adil_synth_fp8. */
 int adil_abi_version(void);
 
 /* Largest K (atoms) the kernels support. */
@@ -69,6 +70,14 @@ int adil_gather_images(const void* src, int src_dtype, const int64_t* index, voi
  * its +-eps clamp (adil.py:480-484) and the final [0,1] clamp (adil.py:567, :623). */
 int adil_synth(const void* x, const float* d, const float* vp, void* out, int B, int P, int K, int dtype,
                float delta_clamp, int pixel_clamp, void* stream);
+
+/* Precision variant of adil_synth for BASELINE.json configs[4] ("fp8 D.V MFMA on CDNA4"; no reference counterpart —
+ * the reference contracts in fp32, adil.py:25): both operands of the contraction are converted to fp8 (OCP e4m3) on the
+ * fly, the codes scaled by 384 / v_absmax (every |vp| must be <= v_absmax: after update_v the l1 radius eps is such a
+ * bound, adil.py:29-31) and the dictionary by 256 (|D| <= 1 after update_d, adil.py:33-35; larger values saturate);
+ * products accumulate in fp32 and are scaled back before the add / clamps.  Same arguments and fusion as adil_synth. */
+int adil_synth_fp8(const void* x, const float* d, const float* vp, void* out, int B, int P, int K, int dtype,
+                   float v_absmax, float delta_clamp, int pixel_clamp, void* stream);
 
 /* Adjoint of the synthesis in ONE pass over the upstream gradient g = dLoss/d(x+delta):
  *     grad_d  (P x K)  = g^T vp          if grad_d  != NULL   (accumulated into grad_d when accumulate_d)

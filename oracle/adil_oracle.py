@@ -135,6 +135,16 @@ def synth(x: Tensor, d: Tensor, v_rows: Tensor) -> Tensor:
     return x + dv
 
 
+def synth_fp8(x: Tensor, d: Tensor, v_rows: Tensor, v_absmax: float) -> Tensor:
+    """Restatement of the fp8 precision variant of the synthesis (include/adil_hip.h adil_synth_fp8; no reference
+    counterpart, the reference contracts in fp32 at adil.py:25): codes scaled by 384 / v_absmax, dictionary by 256,
+    both rounded to OCP e4m3 (round to nearest even, saturating at +-448), exact products, scaled back, added to x."""
+    sv, sd = 384.0 / float(v_absmax), 256.0
+    q = lambda t: t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).double()
+    dv = q(v_rows * sv) @ q(dict_matrix(d) * sd).t() / (sv * sd)
+    return (x.double() + dv.reshape(x.shape)).to(torch.float32)
+
+
 def grad_dv(g: Tensor, d: Tensor, v_rows: Tensor) -> Tuple[Tensor, Tensor]:
     """Adjoint of synth for an upstream gradient g = dLoss/d(x+dv):
     grad_d = g^T v_rows  (P x K, as (C,H,W,K));  grad_v_rows = g D  (B x K)."""

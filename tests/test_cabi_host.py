@@ -264,3 +264,19 @@ def test_adil_constructor_surface_without_data(tmp_path):
     lg = torch.tensor([[1.0, 3.0, -2.0], [-1.0, -3.0, -2.0]])
     out = atk.f_loss(lg, torch.tensor([1, 0]))
     assert out.tolist() == [2.0, -1.0]               # second row: other logits negative -> max is the zeroed label (Q5)
+
+
+def test_vit_patch_embedding_is_the_convolution():
+    """zoo.VisionTransformer computes conv_proj as an unfold + GEMM (same parameters): identical function, and its input
+    gradient equals the convolution's."""
+    from dl_attack_on_imagenet_amd import zoo
+    torch.manual_seed(0)
+    net = zoo.VisionTransformer(image_size=64, layers=1, heads=4, dim=64, mlp_dim=128, num_classes=5)
+    x = torch.rand(2, 3, 64, 64, requires_grad=True)
+    a = net._patch_embed(x)
+    b = net.conv_proj(x).reshape(2, 64, -1).permute(0, 2, 1)
+    assert float((a - b).abs().max()) < 1e-5
+    w = torch.randn_like(a)
+    (ga,) = torch.autograd.grad((a * w).sum(), x)
+    (gb,) = torch.autograd.grad((b * w).sum(), x)
+    assert float((ga - gb).abs().max()) < 1e-5

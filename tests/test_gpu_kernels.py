@@ -474,3 +474,67 @@ def test_zstep_fused_vs_unfused(shape):
         assert float((zf.cpu() - zr).abs().mean()) <= 1e-7
         assert abs(float(delta) - float((zr - prev).abs().max())) <= 5e-5
     close(mf, st.m, 1e-5); close(sf, st.v, 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(5, 3, 7, 9, 3), (33, 3, 16, 16, 10), (64, 3, 20, 12, 50), (40, 3, 8, 8, 100), (70, 3, 32, 32, 128)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_synth_fp8_operands(shape, dt):
+    """adil_synth_fp8 (configs[4]: fp8 D.V MFMA) against the oracle's restatement of the quantised contraction (operands
+    rounded to OCP e4m3 after scaling, exact products, fp32 accumulation): agreement to fp32 accumulation error / one
+    ulp of the stream type; and against the exact fp32 synthesis within what 3 mantissa bits per operand allow."""
+    b, c, h, w, k = shape
+    eps = 8 / 255
+    gen = torch.Generator().manual_seed(sum(shape) + 7)
+    d = -1 + 2 * torch.rand(c, h, w, k, generator=gen)
+    v = O.project_onto_l1_ball(torch.randn(b, k, generator=gen) * 0.02, eps)            # |v| <= eps, rows in the l1 ball
+    x = torch.rand(b, c, h, w, generator=gen).to(dt).float()
+    vp = ops().pack_codes(v.to(DEV), None, b)
+    out = ops().synth(x.to(DEV).to(dt), d.to(DEV), vp, b, fp8_absmax=eps)
+    assert out.dtype == dt
+    want = O.synth_fp8(x, d, v, eps)
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 0.0          # outputs in [0, 1 + eps]: half a bf16 ulp at 1.0 = 2^-8
+    close(out.float(), want, 5e-6 + ulp, "fp8 synth vs quantised oracle")
+    exact = _oracle_synth(x, d, v)
+    dv_err = float((want - exact).abs().max())
+    assert dv_err <= 0.15 * eps, dv_err                         # the price of e4m3 operands, well inside the budget
+    clamped = ops().synth(x.to(DEV).to(dt), d.to(DEV), vp, b, fp8_absmax=eps, delta_clamp=0.004, pixel_clamp=True)
+    wantc = (x.double() + (want.double() - x.double()).clamp(-0.004, 0.004)).clamp(0, 1)
+    close(clamped.float(), wantc, 5e-6 + ulp)
+
+
+def test_fp8_synth_learner_vit_b16():
+    """configs[4] path: ViT-B/16 (197 tokens), 100 atoms, bf16 streams, the synthesis contraction on fp8 MFMAs, through
+    DictionaryLearner.step — judged on what the attack is about: fooled counts against the bf16-operand learner on the
+    same inputs (free-running: within 2 of 16 images at every step, teacher-forced from the bf16 learner's state
+    as well), and the perturbations it synthesises within 0.15 eps of the bf16-operand ones."""
+    from dl_attack_on_imagenet_amd import engine, zoo
+    b, k, eps, T = 16, 100, 8 / 255, 6
+    gen = torch.Generator().manual_seed(5)
+    images = torch.rand(b, 3, 224, 224, generator=gen).to(DEV).to(torch.bfloat16)
+    d0 = (-1 + 2 * torch.rand(3, 224, 224, k, generator=gen)).to(DEV)
+    v0 = ops().l1ball_project_(torch.rand(b, k, generator=gen).to(DEV), eps)
+    model = zoo.build_classifier("vit_b_16", seed=1, device=DEV, dtype=torch.bfloat16)
+    index = torch.arange(b, device=DEV)
+    ref = engine.DictionaryLearner(d0.clone(), v0.clone(), eps, 0.01, "logits")
+    fp8 = engine.DictionaryLearner(d0.clone(), v0.clone(), eps, 0.01, "logits", fp8_synth=True)
+    forced = engine.DictionaryLearner(d0.clone(), v0.clone(), eps, 0.01, "logits", fp8_synth=True)
+    f_ref, f_fp8, f_forced, dv_err = [], [], [], 0.0
+    for _ in range(T):
+        for a, bb in ((forced.d, ref.d), (forced.v, ref.v), (forced.m_d, ref.m_d), (forced.s_d, ref.s_d),
+                      (forced.m_v, ref.m_v), (forced.s_v, ref.s_v)):
+            a.copy_(bb)
+        forced.sched_d.t, forced.sched_v.t = ref.sched_d.t, ref.sched_v.t
+        vp = ops().pack_codes(ref.v, None, b)
+        dv_bf = ops().synth(None, ref.d, vp, b, out_shape=images.shape, out_dtype=torch.float32)
+        dv_f8 = ops().synth(None, ref.d, vp, b, out_shape=images.shape, out_dtype=torch.float32, fp8_absmax=eps)
+        dv_err = max(dv_err, float((dv_bf - dv_f8).abs().max()))
+        f_forced.append(int(forced.step(model, images, index)[1]))
+        f_ref.append(int(ref.step(model, images, index)[1]))
+        f_fp8.append(int(fp8.step(model, images, index)[1]))
+    print("fp8 ViT-B/16: fooled bf16 %s fp8 %s teacher-forced fp8 %s, max |dv_fp8 - dv_bf16| = %.2e (eps %.2e)" %
+          (f_ref, f_fp8, f_forced, dv_err, eps))
+    assert f_ref[-1] >= 8                                       # the attack works on this target
+    assert max(abs(a - c) for a, c in zip(f_ref, f_fp8)) <= 2
+    assert max(abs(a - c) for a, c in zip(f_ref, f_forced)) <= 2
+    assert dv_err <= 0.15 * eps
+    assert float(fp8.d.abs().max()) <= 1.0 and float(fp8.v.abs().sum(1).max()) <= eps * (1 + 1e-5)
