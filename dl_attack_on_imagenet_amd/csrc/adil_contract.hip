@@ -698,11 +698,17 @@ __global__ __launch_bounds__(256) void zstep_mfma_kernel(float* __restrict__ z, 
                                                          float* __restrict__ sq, const float* __restrict__ d,
                                                          const float* __restrict__ vp, int B, int P, int K, int Kp,
                                                          AdamWHyper hy, float lo, float hi, float* max_abs_delta,
-                                                         int tile0) {
+                                                         int tile0, const float* skip_if_below, float skip_threshold,
+                                                         float* clear) {
     using M = Mma<float>;
     using Frag = M::Frag;
     using DI = DImg<float>;
     using BP = BufPx<float>;
+    // device-side stop test of the solver loop (adil.py:559): once the previous iteration's max|dz| fell below the
+    // threshold every later launch is a no-op, so the host may look at the flag only every few iterations and still
+    // return exactly the iterate the reference breaks at
+    if (skip_if_below != nullptr && *skip_if_below < skip_threshold) return;
+    if (clear != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *clear = 0.0f;   // only one of the two range launches gets it
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sd = reinterpret_cast<bf16_t*>(smem_raw);            // [3][128][Ks] bf16: the h, m, l planes of D_dagger
     const int Ks = Kp + DPAD;
@@ -1604,21 +1610,22 @@ extern "C" int adil_grad(const void* g, const float* d, const float* vp, float* 
 template <bool FAST>
 static int launch_zstep_range(float* z, float* m, float* sq, const float* d, const float* vp, int B, int P, int K,
                               AdamWHyper hy, float lo, float hi, float* max_abs_delta, int tile0, int ntiles,
-                              hipStream_t st) {
+                              const float* skip_if_below, float skip_threshold, float* clear, hipStream_t st) {
     if (ntiles <= 0) return 0;
     const int Kp = round_up(K, 16);
     const size_t lds = (size_t)DImg<float>::PLANES * SYNTH_TILE * (Kp + DPAD) * sizeof(bf16_t);
     int rc = set_lds((const void*)zstep_mfma_kernel<FAST>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((zstep_mfma_kernel<FAST>), dim3(ntiles), dim3(256), lds, st, z, m, sq, d, vp, B, P, K, Kp, hy, lo, hi,
-                       max_abs_delta, tile0);
+                       max_abs_delta, tile0, skip_if_below, skip_threshold, clear);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, const float* gvp, int B, int P, int K,
                           float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi,
-                          float* max_abs_delta, void* stream) {
+                          float* max_abs_delta, const float* skip_if_below, float skip_threshold, float* clear,
+                          void* stream) {
     ADIL_ENTER();
     if (!z || !m || !s || !dpinv_t || !gvp || B <= 0 || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     AdamWHyper hy{decay, b1, b2, eps, step_size, bc2_sqrt};
@@ -1626,8 +1633,10 @@ extern "C" int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, co
                      (P <= (1 << 23));                           // 32-row blocks addressable with 32-bit byte offsets
     const int ntiles = (P + SYNTH_TILE - 1) / SYNTH_TILE;
     const int nfast = vec ? P / SYNTH_TILE : 0;
-    int rc = launch_zstep_range<true>(z, m, s, dpinv_t, gvp, B, P, K, hy, lo, hi, max_abs_delta, 0, nfast, (hipStream_t)stream);
+    // `clear` is written by the first launch only (tile0 == 0 exists in exactly one of the two ranges)
+    int rc = launch_zstep_range<true>(z, m, s, dpinv_t, gvp, B, P, K, hy, lo, hi, max_abs_delta, 0, nfast, skip_if_below,
+                                      skip_threshold, nfast > 0 ? clear : nullptr, (hipStream_t)stream);
     if (rc) return rc;
     return launch_zstep_range<false>(z, m, s, dpinv_t, gvp, B, P, K, hy, lo, hi, max_abs_delta, nfast, ntiles - nfast,
-                                     (hipStream_t)stream);
+                                     skip_if_below, skip_threshold, nfast > 0 ? nullptr : clear, (hipStream_t)stream);
 }

@@ -108,7 +108,11 @@ __global__ __launch_bounds__(256) void adamw_l1ball_kernel(float* __restrict__ v
                                                            int32_t* __restrict__ pos, float* __restrict__ m,
                                                            float* __restrict__ s, int N, int K, AdamWHyper h,
                                                            float radius, float* max_abs_delta, int do_adam,
-                                                           int reset_pos) {
+                                                           int reset_pos, const float* skip_if_below,
+                                                           float skip_threshold, float* clear) {
+    // device-side stop test of the solver loop (adil.py:614), see zstep_mfma_kernel
+    if (skip_if_below != nullptr && *skip_if_below < skip_threshold) return;
+    if (clear != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *clear = 0.0f;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= N) return;                          // whole wave exits together
@@ -394,7 +398,7 @@ static inline int stream_grid(size_t work_items, int per_block) {
     return (int)b;
 }
 
-extern "C" int adil_abi_version(void) { return 3; }
+extern "C" int adil_abi_version(void) { return 4; }
 extern "C" int adil_max_atoms(void) { return ADIL_MAX_ATOMS; }
 
 extern "C" int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, int32_t* pos,
@@ -466,26 +470,29 @@ extern "C" int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, 
 
 static int launch_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, float* m, float* s, int N, int K,
                                AdamWHyper h, float radius, float* max_abs_delta, int do_adam, int reset_pos,
-                               hipStream_t st) {
+                               hipStream_t st, const float* skip_if_below = nullptr, float skip_threshold = 0.0f,
+                               float* clear = nullptr) {
     const dim3 grid((N + 3) / 4), block(256);
     if (K <= 64)
         hipLaunchKernelGGL(adamw_l1ball_kernel<1>, grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
-                           max_abs_delta, do_adam, reset_pos);
+                           max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear);
     else
         hipLaunchKernelGGL(adamw_l1ball_kernel<2>, grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
-                           max_abs_delta, do_adam, reset_pos);
+                           max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int adil_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, int reset_pos, float* m, float* s, int N,
                                  int K, float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt,
-                                 float radius, float* max_abs_delta, void* stream) {
+                                 float radius, float* max_abs_delta, const float* skip_if_below, float skip_threshold,
+                                 float* clear, void* stream) {
     ADIL_ENTER();
     if (!v || !m || !s || N <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     if (!grad_vb && !pos) return ADIL_EINVAL;      // without a slot table every row reads its own gradient row
     AdamWHyper h{decay, b1, b2, eps, step_size, bc2_sqrt};
-    return launch_adamw_l1ball(v, grad_vb, pos, m, s, N, K, h, radius, max_abs_delta, 1, reset_pos, (hipStream_t)stream);
+    return launch_adamw_l1ball(v, grad_vb, pos, m, s, N, K, h, radius, max_abs_delta, 1, reset_pos, (hipStream_t)stream,
+                               skip_if_below, skip_threshold, clear);
 }
 
 extern "C" int adil_l1ball_project(float* x, int N, int K, float radius, void* stream) {

@@ -20,6 +20,7 @@ from . import ops
 from .dist import DictGradReducer
 
 Tensor = torch.Tensor
+STOP_POLL = 4        # the solvers look at the device-side stop flag (one host sync) every STOP_POLL iterations
 
 
 # --------------------------------------------------------------------------- #
@@ -183,17 +184,16 @@ def solve_codes_adamw(model, images: Tensor, d: Tensor, eps: float, loss: str = 
     sched = ops.AdamWSchedule(1e-2)
     if labels is None:
         labels = predict(model, images)                                                  # adil.py:598 (constant)
-    delta = torch.zeros(1, dtype=torch.float32, device=images.device)
+    stop = ops.StopTest(images.device, 1e-6)                                             # adil.py:614, on the device
     iters = 0
-    for _ in range(int(max_iter)):
+    for it in range(int(max_iter)):
         iters += 1
         vp = ops.pack_codes(v, None, b)
         xt = ops.synth(images, d, vp, b)
         _, _, g = input_gradient(model, xt, labels, loss, coeff, kappa, ce_reduction)
         _, gvb = ops.grad(g, d, None, b, want_d=False, want_v=True)
-        delta.zero_()
-        ops.adamw_l1ball_(v, gvb, None, m, s, sched.next(), eps, max_abs_delta=delta)      # adil.py:609-610
-        if float(delta) < 1e-6:                                                          # adil.py:614
+        ops.adamw_l1ball_(v, gvb, None, m, s, sched.next(), eps, stop=stop)                # adil.py:609-610
+        if (it + 1) % STOP_POLL == 0 and stop.converged():     # launches after the converged one are no-ops
             break
     vproj = v.clone()
     if norm == "l2":
@@ -238,26 +238,25 @@ class DDragueSolver:
         self.m, self.s = torch.zeros_like(self.z), torch.zeros_like(self.z)
         self.sched = ops.AdamWSchedule(1e-2)
         self.labels = predict(model, self.images) if labels is None else labels        # adil.py:539 (constant)
-        self.delta = torch.zeros(1, dtype=torch.float32, device=self.images.device)
+        self.stop = ops.StopTest(self.images.device, 1e-6)                               # adil.py:559, on the device
         self.iters = 0
 
     def codes(self) -> Tensor:
         _, vcode = ops.grad(self.z, self.dpt, None, self.b, want_d=False, want_v=True)  # v = z D_dagger^T (K6)
         return vcode
 
-    def iterate(self) -> Tensor:
-        """One iteration; returns max|dz| as a 1-element device tensor (the stop test of adil.py:559 reads it)."""
+    def iterate(self) -> None:
+        """One iteration.  The stop test of adil.py:559 runs on the device (ops.StopTest): after the iteration whose
+        max|dz| falls below 1e-6 the z-step launches do nothing; `self.stop.converged()` polls it."""
         b = self.b
         self.iters += 1
         vp = ops.pack_codes(self.codes(), None, b)                                       # adil.py:542
         xt = ops.synth(self.images, self.d, vp, b)                                       # adil.py:543-544
         _, _, g = input_gradient(self.model, xt, self.labels, self.loss, self.coeff, self.kappa, "mean")
         _, gv = ops.grad(g, self.d, None, b, want_d=False, want_v=True)                  # dL/dv = g D
-        self.delta.zero_()
         # dL/dz = (dL/dv) D_dagger is formed inside the kernel and consumed by AdamW(z) + clamp: never materialised (K8)
         ops.zstep_(self.z, self.m, self.s, self.dpt, ops.pack_codes(gv, None, b), b, self.sched.next(), -self.eps,
-                   self.eps, max_abs_delta=self.delta)
-        return self.delta
+                   self.eps, stop=self.stop)
 
     def result(self) -> Tuple[Tensor, Tensor]:
         vcode = self.codes()
@@ -271,8 +270,9 @@ def solve_ddrague(model, images: Tensor, d: Tensor, eps: float, steps_inference:
     """forward_supervised_DDrague (adil.py:508-567): optimise z (B,C,H,W) with AdamW(1e-2), the perturbation
     being D D_dagger z; z is clamped to +-eps (the perturbation itself is not — quirk Q6)."""
     solver = DDragueSolver(model, images, d, eps, loss, targeted, kappa, pinv, labels)
-    for _ in range(int(steps_inference)):
-        if float(solver.iterate()) < 1e-6:                                               # adil.py:559
+    for it in range(int(steps_inference)):
+        solver.iterate()
+        if (it + 1) % STOP_POLL == 0 and solver.stop.converged():                        # adil.py:559
             break
     adv, vcode = solver.result()
     if return_trace:

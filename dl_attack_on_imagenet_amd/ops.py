@@ -95,6 +95,32 @@ class AdamWSchedule:
         return AdamWScalars(1.0 - self.lr * self.wd, self.b1, self.b2, self.eps, self.lr / bc1, math.sqrt(bc2))
 
 
+class StopTest:
+    """Device-side stop test of the inference solvers (`if max|x - x_old| < 1e-6: break`, adil.py:559, :614).
+
+    Three rotating fp32 slots: iteration t accumulates its max|delta| into slot t%3, does nothing at all if slot
+    (t-1)%3 — the previous iteration's maximum — is already below the threshold, and clears slot (t+1)%3 for its
+    successor.  Once an iteration converges every later launch is therefore a no-op: the host can poll `converged()`
+    (a device->host sync) only every few iterations and still stop on exactly the iterate the reference breaks at."""
+
+    def __init__(self, device, threshold: float = 1e-6):
+        self.slots = torch.tensor([0.0, 0.0, 3.0e38], dtype=torch.float32, device=device)
+        self.threshold, self.t = float(threshold), 0
+
+    def _slot(self, i: int) -> c_void_p:
+        return c_void_p(self.slots.data_ptr() + 4 * (i % 3))
+
+    def launch_args(self):
+        """(max_abs_delta, skip_if_below, skip_threshold, clear) of the launch of iteration t; advances t."""
+        t = self.t
+        self.t += 1
+        return self._slot(t), self._slot(t + 2), self.threshold, self._slot(t + 1)
+
+    def converged(self) -> bool:
+        """True once the last launched iteration (or an earlier one) moved nothing by the threshold or more."""
+        return self.t > 0 and float(self.slots[(self.t - 1) % 3]) < self.threshold
+
+
 # --------------------------------------------------------------------------- #
 def pack_codes(v: Tensor, index: Optional[Tensor], batch: Optional[int] = None, pos: Optional[Tensor] = None) -> Tensor:
     """vp [roundup(B,32)][roundup(K,16)] = zero-padded v[index] (adil.py:25 `self.v[index, :]`).
@@ -223,8 +249,18 @@ def adamw_clamp_(p: Tensor, g: Tensor, m: Tensor, s: Tensor, h: AdamWScalars, lo
                                     _ptr(max_abs_delta), _stream()), "adil_adamw_clamp")
 
 
+def _stop_args(max_abs_delta: Optional[Tensor], stop: Optional[StopTest]):
+    if stop is not None:
+        if max_abs_delta is not None:
+            raise ValueError("pass either max_abs_delta or stop")
+        return stop.launch_args()
+    if max_abs_delta is not None:
+        _dev(max_abs_delta, "max_abs_delta", torch.float32)
+    return _ptr(max_abs_delta), c_void_p(0), 0.0, c_void_p(0)
+
+
 def zstep_(z: Tensor, m: Tensor, s: Tensor, dpinv_t: Tensor, gvp: Tensor, batch: int, h: AdamWScalars, lo: float,
-           hi: float, max_abs_delta: Optional[Tensor] = None) -> None:
+           hi: float, max_abs_delta: Optional[Tensor] = None, stop: Optional[StopTest] = None) -> None:
     """In-place fused DDrague step: gz = gvp D_dagger formed on the fly, AdamW(z), clamp, max|dz| (adil.py:551-559)."""
     lib = _lib.load()
     for name, t in (("z", z), ("m", m), ("s", s), ("dpinv_t", dpinv_t), ("gvp", gvp)):
@@ -232,14 +268,14 @@ def zstep_(z: Tensor, m: Tensor, s: Tensor, dpinv_t: Tensor, gvp: Tensor, batch:
     p, k = dict_shape(dpinv_t)
     if not (z.numel() == m.numel() == s.numel() == batch * p) or gvp.shape != (_round_up(batch, 32), _round_up(k, 16)):
         raise ValueError("zstep_: operand shapes do not match (B, P, K)")
-    if max_abs_delta is not None:
-        _dev(max_abs_delta, "max_abs_delta", torch.float32)
+    dmax, skip, thr, clear = _stop_args(max_abs_delta, stop)
     _lib.check(lib.adil_zstep(_ptr(z), _ptr(m), _ptr(s), _ptr(dpinv_t), _ptr(gvp), batch, p, k, h.decay, h.b1, h.b2, h.eps,
-                              h.step_size, h.bc2_sqrt, float(lo), float(hi), _ptr(max_abs_delta), _stream()), "adil_zstep")
+                              h.step_size, h.bc2_sqrt, float(lo), float(hi), dmax, skip, thr, clear, _stream()), "adil_zstep")
 
 
 def adamw_l1ball_(v: Tensor, grad_vb: Optional[Tensor], pos: Optional[Tensor], m: Tensor, s: Tensor, h: AdamWScalars,
-                  radius: float, max_abs_delta: Optional[Tensor] = None, reset_pos: bool = False) -> None:
+                  radius: float, max_abs_delta: Optional[Tensor] = None, reset_pos: bool = False,
+                  stop: Optional[StopTest] = None) -> None:
     """In-place AdamW on ALL rows of v (zero gradient outside the batch) + l1-ball projection
     (adil.py:186-187; radius < 0 skips the projection).  pos is the batch-slot table written by pack_codes; with
     reset_pos the kernel hands it back all -1.  grad_vb None = no row of this v is in the batch (pos all -1)."""
@@ -259,11 +295,10 @@ def adamw_l1ball_(v: Tensor, grad_vb: Optional[Tensor], pos: Optional[Tensor], m
         raise ValueError("without pos, grad_vb must have one row per row of v")
     if m.shape != v.shape or s.shape != v.shape:
         raise ValueError("adamw_l1ball_: shape mismatch")
-    if max_abs_delta is not None:
-        _dev(max_abs_delta, "max_abs_delta", torch.float32)
+    dmax, skip, thr, clear = _stop_args(max_abs_delta, stop)
     _lib.check(lib.adil_adamw_l1ball(_ptr(v), _ptr(grad_vb), _ptr(pos), int(bool(reset_pos)), _ptr(m), _ptr(s), n, k,
                                      h.decay, h.b1, h.b2, h.eps, h.step_size, h.bc2_sqrt, float(radius),
-                                     _ptr(max_abs_delta), _stream()), "adil_adamw_l1ball")
+                                     dmax, skip, thr, clear, _stream()), "adil_adamw_l1ball")
 
 
 def l1ball_project_(x: Tensor, radius: float) -> Tensor:

@@ -40,7 +40,7 @@ extern "C" {
 
 /* ABI version of this header; bumped on any signature change.  2: frozen-classifier entry points.  3: batch-slot table
  * written by adil_pack_codes and consumed + reset by adil_adamw_l1ball, adil_gather_images, adil_spd_inverse,
- * adil_synth_fp8. */
+ * adil_synth_fp8.  4: device-side stop test arguments of adil_zstep / adil_adamw_l1ball. */
 int adil_abi_version(void);
 
 /* Largest K (atoms) the kernels support. */
@@ -104,10 +104,15 @@ int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, float* s, s
  *     gz = gvp D_dagger   (gvp = packed dLoss/dv [Bp][Kp], dpinv_t = D_dagger^T stored P x K like D),
  * is formed in the MFMA accumulators and consumed on the spot by AdamW(z) + clamp[lo,hi] + max|dz|; it never
  * touches HBM.  z, m, s are fp32 B x P.  Replaces `loss.backward()` through the two tensordots (adil.py:542-543),
- * `optimise.step()`, the clamp (adil.py:555) and the stop test (adil.py:559). */
+ * `optimise.step()`, the clamp (adil.py:555) and the stop test (adil.py:559).
+ * Device-side stop test (all three optional, adil.py:559 `if max|z - z_old| < 1e-6: break`): if skip_if_below is
+ * given and *skip_if_below < skip_threshold the call does nothing; `clear` (a float) is set to 0.  With three floats
+ * s[0..2] = {0, 0, +big} and iteration t passing max_abs_delta = &s[t%3], skip_if_below = &s[(t+2)%3], clear =
+ * &s[(t+1)%3], every launch after the converged one is a no-op, so the host may read s[t%3] only every few iterations
+ * and still end on exactly the iterate the reference breaks at. */
 int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, const float* gvp, int B, int P, int K, float decay,
                float b1, float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi, float* max_abs_delta,
-               void* stream);
+               const float* skip_if_below, float skip_threshold, float* clear, void* stream);
 
 /* Fused AdamW step on ALL N rows of the code matrix + row-wise l1-ball projection.
  * The gradient is non-zero only for the rows of the current batch: pos[n] = b if row n is
@@ -118,10 +123,11 @@ int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, const float* 
  * grad_vb may be NULL when pos is given and holds no slot (a rank with an empty shard of the batch).
  * radius < 0 skips the projection.
  * Replaces optimise.step() + update_v (adil.py:186-187 with :29-31 and utils.py:21-41),
- * and the same pair in forward_supervised_AdamW (adil.py:609-610, :614). */
+ * and the same pair in forward_supervised_AdamW (adil.py:609-610, :614); skip_if_below / skip_threshold / clear are the
+ * device-side stop test described at adil_zstep (adil.py:614). */
 int adil_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, int reset_pos, float* m, float* s, int N, int K,
                       float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt, float radius,
-                      float* max_abs_delta, void* stream);
+                      float* max_abs_delta, const float* skip_if_below, float skip_threshold, float* clear, void* stream);
 
 /* Row-wise Euclidean projection onto the l1 ball, in place: project_onto_l1_ball (utils.py:21-41). */
 int adil_l1ball_project(float* x, int N, int K, float radius, void* stream);

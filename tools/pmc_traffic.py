@@ -29,7 +29,7 @@ def per_kernel(dirname, counter):
 
 def short(name):
     m = re.search(r"(synth_mfma_kernel|grad_fused_mfma_kernel|grad_d_mfma_kernel|grad_v_mfma_kernel|grad_v_reduce_kernel|adamw_clamp_kernel|"
-                  r"adamw_l1ball_kernel|pack_codes_kernel|transpose_codes_kernel)<([^>]*)", name)
+                  r"adamw_l1ball_kernel|pack_codes_kernel|transpose_codes_kernel|zstep_mfma_kernel|gather_images_kernel)<([^>]*)", name)
     if m:
         return f"{m.group(1)}<{m.group(2).split('>')[0]}>"
     if "grad_v_reduce_kernel" in name:
@@ -57,12 +57,15 @@ def main():
               "grad": [k for k in rows if k.startswith(("grad_fused_mfma", "grad_v_reduce", "transpose_codes"))],
               "adamw_clamp_": [k for k in rows if k.startswith("adamw_clamp")],
               "adamw_l1ball_": [k for k in rows if k.startswith("adamw_l1ball")],
+              "zstep_": [k for k in rows if k.startswith("zstep_mfma")],
+              "grad[z D_dagger^T]": [k for k in rows if k.startswith("grad_v_mfma_kernel<float")],
               "pack_codes": [k for k in rows if k.startswith("pack_codes")]}
     result = {"_source": {"fetch": fp, "write": wp, "correction": "hbm = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950)"},
               "_kernels": rows}
     for g, ks in groups.items():
         # bf16 instantiations only (the bench workload): template arg 't' = unsigned short
-        sel = [k for k in ks if "<unsigned short" in k or "<" not in k or g in ("adamw_clamp_", "adamw_l1ball_", "pack_codes")]
+        sel = [k for k in ks if "<unsigned short" in k or "<" not in k or
+               g in ("adamw_clamp_", "adamw_l1ball_", "pack_codes", "zstep_", "grad[z D_dagger^T]")]
         if sel:
             result[g] = sum(rows[k]["hbm_bytes"] for k in sel)
     json.dump(result, open(out, "w"), indent=1)

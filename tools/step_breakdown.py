@@ -4,8 +4,12 @@ path = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'synth_mfma_kernel' in r['Kernel_Name']]
+OURS = ("synth", "grad_", "adamw", "pack_codes", "l1ball", "zstep", "gather_images", "transpose_codes", "spd_inverse",
+        "gram", "rightmul", "image_metrics")
 def short(n):
     n = n.strip('"')
+    m0 = re.match(r'(?:void )?(?:\(anonymous namespace\)::)?(\w+_kernel)\b', n)
+    if m0 and any(k in m0.group(1) for k in OURS): return m0.group(1)      # "adamw_clamp_kernel" is not a ReLU clamp
     for key in ('stem_conv_fwd_kernel', 'stem_conv_bwd_kernel', 'stem_pool_bwd_kernel', 'maxpool_fwd_kernel',
                 'pw_conv_fwd_kernel', 'pw_conv_bwd_kernel', 'conv3x3_kernel'):
         if key in n: return key
