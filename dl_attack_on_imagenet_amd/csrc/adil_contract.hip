@@ -707,7 +707,11 @@ __global__ __launch_bounds__(256) void zstep_mfma_kernel(float* __restrict__ z, 
     // device-side stop test of the solver loop (adil.py:559): once the previous iteration's max|dz| fell below the
     // threshold every later launch is a no-op, so the host may look at the flag only every few iterations and still
     // return exactly the iterate the reference breaks at
-    if (skip_if_below != nullptr && *skip_if_below < skip_threshold) return;
+    if (skip_if_below != nullptr && *skip_if_below < skip_threshold) {
+        // stay stopped: this iteration's own slot reads 0 to the next launch, whatever an earlier round left in it
+        if (max_abs_delta != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *max_abs_delta = 0.0f;
+        return;
+    }
     if (clear != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *clear = 0.0f;   // only one of the two range launches gets it
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sd = reinterpret_cast<bf16_t*>(smem_raw);            // [3][128][Ks] bf16: the h, m, l planes of D_dagger

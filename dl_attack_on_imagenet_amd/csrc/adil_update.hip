@@ -111,7 +111,10 @@ __global__ __launch_bounds__(256) void adamw_l1ball_kernel(float* __restrict__ v
                                                            int reset_pos, const float* skip_if_below,
                                                            float skip_threshold, float* clear) {
     // device-side stop test of the solver loop (adil.py:614), see zstep_mfma_kernel
-    if (skip_if_below != nullptr && *skip_if_below < skip_threshold) return;
+    if (skip_if_below != nullptr && *skip_if_below < skip_threshold) {
+        if (max_abs_delta != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *max_abs_delta = 0.0f;   // stay stopped
+        return;
+    }
     if (clear != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *clear = 0.0f;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);

@@ -106,7 +106,8 @@ int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, float* s, s
  * touches HBM.  z, m, s are fp32 B x P.  Replaces `loss.backward()` through the two tensordots (adil.py:542-543),
  * `optimise.step()`, the clamp (adil.py:555) and the stop test (adil.py:559).
  * Device-side stop test (all three optional, adil.py:559 `if max|z - z_old| < 1e-6: break`): if skip_if_below is
- * given and *skip_if_below < skip_threshold the call does nothing; `clear` (a float) is set to 0.  With three floats
+ * given and *skip_if_below < skip_threshold the call changes nothing and sets *max_abs_delta = 0 (so its successor skips
+ * as well); otherwise `clear` (a float) is set to 0.  With three floats
  * s[0..2] = {0, 0, +big} and iteration t passing max_abs_delta = &s[t%3], skip_if_below = &s[(t+2)%3], clear =
  * &s[(t+1)%3], every launch after the converged one is a no-op, so the host may read s[t%3] only every few iterations
  * and still end on exactly the iterate the reference breaks at. */

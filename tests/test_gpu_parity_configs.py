@@ -12,6 +12,7 @@
 The numbers each test prints are copied into profiles/r02_parity_configs.md and quoted in DESIGN.md §2."""
 import json
 import os
+import time
 
 import pytest
 import torch
@@ -19,13 +20,14 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+STAMP = time.strftime("%Y%m%dT%H%M%S")          # one file per test process: earlier runs' numbers are kept
 
 
 def _note(name, payload):
     """Keep the measured parity numbers next to the other GPU-run artefacts (gpurun_out/ is merged back)."""
     try:
         os.makedirs(OUT, exist_ok=True)
-        with open(os.path.join(OUT, "parity_configs.jsonl"), "a") as f:
+        with open(os.path.join(OUT, f"parity_configs_{STAMP}.jsonl"), "a") as f:
             f.write(json.dumps({"test": name, **payload}) + "\n")
     except OSError:
         pass
