@@ -312,8 +312,7 @@ def main():
     timer.enabled = False
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax)
+        elapsed = float(adist.all_reduce_(tmax, torch.distributed.ReduceOp.MAX))
 
     if args.mode == "inference":
         adv, _ = solver.result()

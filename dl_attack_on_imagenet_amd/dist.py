@@ -75,6 +75,21 @@ def global_epoch_batches(n: int, batch_size: int, world: int, seed: int, epoch: 
     return [[i for p in perms for i in p[s * chunk:(s + 1) * chunk]] for s in range(steps)]
 
 
+def _staged(t: torch.Tensor, group=None) -> bool:
+    """gloo rehearsals (ADIL_DIST_BACKEND=gloo) move device tensors through the host; RCCL works on them in place."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_(t: torch.Tensor, op=dist.ReduceOp.SUM, group=None) -> torch.Tensor:
+    if _staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 class DictGradReducer:
     """The single collective of a learning step: grad_d <- sum over ranks (in place)."""
 
@@ -85,18 +100,21 @@ class DictGradReducer:
         self.world = dist.get_world_size(group)
 
     def all_reduce_(self, grad_d: torch.Tensor) -> torch.Tensor:
-        dist.all_reduce(grad_d, op=dist.ReduceOp.SUM, group=self.group)
-        return grad_d
+        return all_reduce_(grad_d, dist.ReduceOp.SUM, self.group)
 
     def sum_scalars(self, *values) -> List[float]:
         """Per-epoch bookkeeping (loss, fooled counts): mirrors dist.reduce at adil.py:418-419."""
         dev = values[0].device if isinstance(values[0], torch.Tensor) else torch.device("cpu")
         t = torch.stack([torch.as_tensor(v, dtype=torch.float64, device=dev).reshape(()) for v in values])
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t.tolist()
+        return all_reduce_(t, dist.ReduceOp.SUM, self.group).tolist()
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
-        dist.broadcast(t, src=src, group=self.group)
+        if _staged(t, self.group):
+            h = t.cpu()
+            dist.broadcast(h, src=src, group=self.group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=src, group=self.group)
         return t
 
     def gather_rows(self, rows: torch.Tensor, counts: List[int]) -> torch.Tensor:
@@ -105,6 +123,8 @@ class DictGradReducer:
         width = max(counts)
         pad = torch.zeros((width,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
         pad[:rows.shape[0]] = rows
+        if _staged(pad, self.group):
+            pad = pad.cpu()
         parts = [torch.empty_like(pad) for _ in counts]
         dist.all_gather(parts, pad, group=self.group)
-        return torch.cat([p[:c] for p, c in zip(parts, counts)])
+        return torch.cat([p[:c] for p, c in zip(parts, counts)]).to(rows.device)
