@@ -1043,12 +1043,14 @@ __global__ __launch_bounds__(NW * 64) void grad_v_mfma_kernel(const T* __restric
         }
         if (more) gv_write_d<T, AT, NW, FAST>(sdt + (buf ^ 1) * DBUF, tile + 1, P, K, tid, dreg);
     }
-    if (active) {                                                 // partial sums of this workgroup: slab[wg][row][atom]
-        float* dst = slab + (size_t)blockIdx.x * Bp * KA;
+    if (active) {                                                 // partial sums of this workgroup: slab[wg][row][atom < K]
+        float* dst = slab + (size_t)blockIdx.x * Bp * K;
 #pragma unroll
         for (int at = 0; at < AT; ++at)
+            if (at * 32 + c < K) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[(size_t)(b0 + c_row(r, h)) * KA + at * 32 + c] = accv[at][r];
+                for (int r = 0; r < 16; ++r) dst[(size_t)(b0 + c_row(r, h)) * K + at * 32 + c] = accv[at][r];
+            }
     }
 }
 
@@ -1254,11 +1256,13 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
     for (int rb = 0; rb < RB; ++rb) {
         const int b0 = (w * RB + rb) * 32;
         if (b0 < Bp) {
-            float* dst = slab + (size_t)blockIdx.x * Bp * KA;
+            float* dst = slab + (size_t)blockIdx.x * Bp * K;      // compact rows of K atoms: no padded columns cross HBM
 #pragma unroll
             for (int at = 0; at < AT; ++at)
+                if (at * 32 + c < K) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dst[(size_t)(b0 + c_row(r, h)) * KA + at * 32 + c] = accv[rb][at][r];
+                    for (int r = 0; r < 16; ++r) dst[(size_t)(b0 + c_row(r, h)) * K + at * 32 + c] = accv[rb][at][r];
+                }
         }
     }
 }
@@ -1279,7 +1283,7 @@ __global__ __launch_bounds__(256) void transpose_codes_kernel(const float* __res
 __global__ __launch_bounds__(256) void grad_v_reduce_kernel(const float* __restrict__ slab, int nslabs, int Bp, int KA,
                                                             int B, int K, float* __restrict__ grad_vb) {
     __shared__ float part[4][64];
-    const int e = blockIdx.x * 64 + (threadIdx.x & 63);          // entry of the padded [Bp][KA] matrix
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);          // entry of the [Bp][KA] slab matrix (KA = row stride = K)
     const int grp = threadIdx.x >> 6;
     const size_t stride = (size_t)Bp * KA;
     float acc[8];
@@ -1477,11 +1481,11 @@ static int launch_grad_v(const T* g, const float* d, float* grad_vb, int B, int 
         const T* gc = g + (size_t)r0 * P;
         int rc = launch_grad_v_range<T, AT, true>(gc, d, slab, rows, rows_p, P, K, 0, nfast, nwg_fast, tpw_fast, st);
         if (rc) return rc;
-        rc = launch_grad_v_range<T, AT, false>(gc, d, slab + (size_t)nwg_fast * rows_p * KA, rows, rows_p, P, K, nfast,
+        rc = launch_grad_v_range<T, AT, false>(gc, d, slab + (size_t)nwg_fast * rows_p * K, rows, rows_p, P, K, nfast,
                                                ntiles, nwg_slow, tpw_slow, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows_p * KA + 63) / 64), dim3(256), 0, st, (const float*)slab,
-                           nwg_fast + nwg_slow, rows_p, KA, rows, K, grad_vb + (size_t)r0 * K);
+        hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows_p * K + 63) / 64), dim3(256), 0, st, (const float*)slab,
+                           nwg_fast + nwg_slow, rows_p, K, rows, K, grad_vb + (size_t)r0 * K);   // slab rows are K wide
         ADIL_CHECK_LAUNCH();
     }
     return 0;
@@ -1556,11 +1560,11 @@ static int launch_grad_fused(const T* g, const float* d, const float* vp, float*
         int rc = launch_grad_fused_range<T, AT, true>(gc, d, vpt + r0, Bp, grad_d, slab, rows, rows_p, P, K, acc_d, 0, nfast,
                                                       nwg_fast, tpw_fast, st);
         if (rc) return rc;
-        rc = launch_grad_fused_range<T, AT, false>(gc, d, vpt + r0, Bp, grad_d, slab + (size_t)nwg_fast * rows_p * KA, rows,
+        rc = launch_grad_fused_range<T, AT, false>(gc, d, vpt + r0, Bp, grad_d, slab + (size_t)nwg_fast * rows_p * K, rows,
                                                    rows_p, P, K, acc_d, nfast, ntiles, nwg_slow, tpw_slow, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows_p * KA + 63) / 64), dim3(256), 0, st, (const float*)slab,
-                           nwg_fast + nwg_slow, rows_p, KA, rows, K, grad_vb + (size_t)r0 * K);
+        hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows_p * K + 63) / 64), dim3(256), 0, st, (const float*)slab,
+                           nwg_fast + nwg_slow, rows_p, K, rows, K, grad_vb + (size_t)r0 * K);   // slab rows are K wide
         ADIL_CHECK_LAUNCH();
     }
     return 0;

@@ -571,3 +571,33 @@ def test_device_side_stop_test_is_exact():
         assert torch.equal(v, v_ref), poll                      # bit-identical to the per-iteration break
         assert stop.converged() and launched >= ref_iters, poll
         assert launched == (T if poll == 1000 else -(-ref_iters // poll) * poll), (poll, launched, ref_iters)
+
+
+@pytest.mark.parametrize("b,k,hw", [(512, 50, 64), (512, 10, 64), (500, 50, 64), (1024, 50, 64), (512, 64, 32),
+                                    (512, 50, 224), (1024, 33, 224)])
+def test_grad_fused_whole_workgroups(b, k, hw):
+    """The fused single pass at the benchmark's workgroup shape (bf16 streams, 512-row workgroups, K <= 64): one, a few
+    and many tiles per workgroup (hw = 32 / 64 / 224), ragged rows inside the last block (500), a second accumulating
+    row chunk (1024), both atom-tile counts, compact slab rows (K not a multiple of 32) — against fp64 matmuls on the
+    device with operands rounded as the kernel rounds them, against the two single-output kernels (different code, same
+    maths), and bitwise reproducible."""
+    gen = torch.Generator().manual_seed(b + k + hw)
+    d = (-1 + 2 * torch.rand(3, hw, hw, k, generator=gen)).to(DEV)
+    v = (torch.randn(b, k, generator=gen) * 0.02).to(DEV)
+    g = torch.randn(b, 3, hw, hw, generator=gen).to(DEV).to(torch.bfloat16)
+    vp = ops().pack_codes(v, None, b)
+    gd, gvb = ops().grad(g, d, vp, b)
+    dq, vq = d.bfloat16().double().reshape(-1, k), v.bfloat16().double()
+    g2 = g.double().reshape(b, -1)
+    p = 3 * hw * hw
+    close(gd.reshape(-1, k), g2.t() @ vq, 5e-5 * b ** 0.5)
+    close(gvb, g2 @ dq, 1e-4 * p ** 0.5)
+    gd_only, _ = ops().grad(g, d, vp, b, want_v=False)
+    _, gv_only = ops().grad(g, d, None, b, want_d=False)
+    close(gd, gd_only, 2e-6 * b ** 0.5 * 4)
+    close(gvb, gv_only, 3e-6 * p ** 0.5 * 4)
+    gd2, gvb2 = ops().grad(g, d, vp, b)
+    assert torch.equal(gd, gd2) and torch.equal(gvb, gvb2)
+    acc = gd.clone()
+    ops().grad(g, d, vp, b, want_v=True, grad_d=acc, accumulate_d=True)
+    close(acc, 2 * gd, 2e-6 * b ** 0.5 * 8)
