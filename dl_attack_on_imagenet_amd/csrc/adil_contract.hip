@@ -1094,13 +1094,12 @@ template <> struct ColFrag<float> {
     }
 };
 
-template <typename T, int AT, int NW, int RB, bool FAST>
+template <typename T, int AT, int NW, int RB, bool FAST, bool ACC>
 __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __restrict__ g, const float* __restrict__ d,
                                                                   const typename Mma<T>::Elem* __restrict__ vpt,
                                                                   int vstride, float* __restrict__ grad_d,
                                                                   float* __restrict__ slab, int B, int Bp, int P, int K,
-                                                                  int accumulate_d, int tile_begin, int tile_end,
-                                                                  int tiles_per_wg) {
+                                                                  int tile_begin, int tile_end, int tiles_per_wg) {
     // NW waves, each owning RB consecutive 32-row batch blocks (RB = 2 keeps the 512-row workgroup at 8 waves, i.e.
     // a 256-register budget per wave: with 16 waves the 128-register cap spills, and a scratch reload behind the
     // prefetched loads drains vmcnt and serialises the stream).
@@ -1174,6 +1173,19 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
                 for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(sg + (i * RPI + lrow) * GS + lcol) = blk[rb][i];
             }
         }
+        // An accumulating launch (second row chunk) needs the old grad_d values of THIS tile at the end of the
+        // iteration.  They are requested here, BEFORE the next tile's loads: vmcnt retires in issue order, so waiting for
+        // them later leaves the younger prefetch in flight (loading them next to the store drained it every iteration).
+        float dold[ACC ? RPW : 1];
+        if constexpr (ACC) {
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int reg = (KS > 1) ? ks * RPW + rr : rr;
+                const int pix = p0 + tp * 32 + c_row(reg, h);
+                const int atom = ta * 32 + c;
+                dold[rr] = grad_d[(size_t)((FAST || pix < P) ? pix : P - 1) * K + (atom < K ? atom : K - 1)];
+            }
+        }
         if (more) {                                               // next tile's loads fly under this tile's MFMAs
             gv_load_d<T, AT, NW, FAST>(d, tile + 1, P, K, tid, dreg);
 #pragma unroll
@@ -1245,7 +1257,7 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
                 const int pix = p0 + tp * 32 + c_row(reg, h);
                 if (atom < K && (FAST || pix < P)) {
                     float* o = grad_d + (size_t)pix * K + atom;
-                    if (accumulate_d) *o += sum; else *o = sum;   // uniform condition
+                    if constexpr (ACC) *o = dold[rr] + sum; else *o = sum;   // old value prefetched at the top
                 }
             }
         }
@@ -1513,10 +1525,17 @@ static int launch_grad_fused_nw(const T* g, const float* d, const typename Mma<T
         return ADIL_EINVAL;
     } else {
         const size_t lds = grad_fused_lds_bytes<T, AT, NW, RB>();
-        int rc = set_lds((const void*)grad_fused_mfma_kernel<T, AT, NW, RB, FAST>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((grad_fused_mfma_kernel<T, AT, NW, RB, FAST>), dim3(nwg), dim3(NW * 64), lds, st, g, d, vpt,
-                           vstride, grad_d, slab, rows, rows_p, P, K, acc_d, tile_begin, tile_end, tiles_per_wg);
+        if (acc_d) {
+            int rc = set_lds((const void*)grad_fused_mfma_kernel<T, AT, NW, RB, FAST, true>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((grad_fused_mfma_kernel<T, AT, NW, RB, FAST, true>), dim3(nwg), dim3(NW * 64), lds, st, g, d,
+                               vpt, vstride, grad_d, slab, rows, rows_p, P, K, tile_begin, tile_end, tiles_per_wg);
+        } else {
+            int rc = set_lds((const void*)grad_fused_mfma_kernel<T, AT, NW, RB, FAST, false>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((grad_fused_mfma_kernel<T, AT, NW, RB, FAST, false>), dim3(nwg), dim3(NW * 64), lds, st, g, d,
+                               vpt, vstride, grad_d, slab, rows, rows_p, P, K, tile_begin, tile_end, tiles_per_wg);
+        }
         ADIL_CHECK_LAUNCH();
         return 0;
     }

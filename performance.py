@@ -10,6 +10,24 @@ import numpy as np
 import torch
 
 from dl_attack_on_imagenet_amd import ops
+from dl_attack_on_imagenet_amd import dist as adist
+
+
+def _rank_world():
+    """(rank, world) of the evaluation: data-parallel over the loader's batches when a process group is initialised
+    (one process per GPU, torchrun env -> dist.init_from_env), else (0, 1).  Evaluation shards trivially: the dictionary
+    is replicated (every rank loads the same file), batch i is attacked and scored by rank i % world, and only the final
+    sums cross ranks (BASELINE.json configs[3])."""
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        return tdist.get_rank(), tdist.get_world_size()
+    return 0, 1
+
+
+def _sum_over_ranks(values, device):
+    """Element-wise sum of a flat list of python floats over all ranks (one small all-reduce)."""
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    return adist.all_reduce_(t).tolist()
 
 
 def get_args(args):
@@ -61,7 +79,10 @@ def performance(attack, model, data, device=torch.device('cpu')):
     (performance.py:154-177)."""
     num_samples, fooling, rmse, mse = 0, 0, 0, 0
     device = attack.device
-    for x, y in data:
+    rank, world = _rank_world()
+    for i, (x, y) in enumerate(data):
+        if i % world != rank:
+            continue
         x, y = x.to(device=device), y.to(device=device)
         keep = model(x).argmax(dim=-1) == y                                  # performance.py:162-164
         x, y = x[keep].contiguous(), y[keep]
@@ -74,6 +95,8 @@ def performance(attack, model, data, device=torch.device('cpu')):
         r, m = _rmse_mse(adversary, x)
         rmse += r
         mse += m
+    if world > 1:
+        num_samples, fooling, rmse, mse = _sum_over_ranks([float(num_samples), fooling, rmse, mse], device)
     print(num_samples)
     return {"fooling_rate": fooling / num_samples, "rmse": rmse / num_samples, "mse": mse / num_samples}
 
@@ -98,7 +121,10 @@ def get_transfer_performance_aux(attack, model_transfer, data, device=torch.devi
     it; sums are divided by the dataset size (performance.py:205-232)."""
     num_samples = len(data.dataset)
     perf = {name: {'fooling_rate': 0., 'rmse': 0., 'mse': 0.} for name in model_transfer.keys()}
-    for x, y in data:
+    rank, world = _rank_world()
+    for i, (x, y) in enumerate(data):
+        if i % world != rank:
+            continue
         x, y = x.to(device=device), y.to(device=device)
         adversary = attack(x, y)
         if isinstance(adversary, tuple):
@@ -111,6 +137,10 @@ def get_transfer_performance_aux(attack, model_transfer, data, device=torch.devi
                                                                      clean=x) / num_samples
             perf[model_name]['rmse'] += r / num_samples
             perf[model_name]['mse'] += m / num_samples
+    if world > 1:
+        keys = [(name, k) for name in perf for k in ('fooling_rate', 'rmse', 'mse')]
+        for (name, k), v in zip(keys, _sum_over_ranks([perf[n][k] for n, k in keys], device)):
+            perf[name][k] = v
     return perf
 
 

@@ -424,3 +424,59 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert out["config"]["global_batch"] == 64 and out["value"] > 0
     assert abs(out["value"] - 2 * 32 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     assert "cpu_baseline" not in out and out["roofline"]["bound"] == "hbm"
+
+
+def test_transfer_evaluation_data_parallel(tmp_path):
+    """configs[3] is a data-parallel evaluation: the dictionary is replicated, batches are dealt to the ranks, only the final
+    sums cross ranks.  Two ranks (gloo rehearsal on this one GPU) through performance.get_transfer_performance reproduce the
+    reference's G15 numbers exactly like the single-process run."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    z = load_golden("g15_transfer")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, ADIL_DIST_BACKEND="gloo", ADIL_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = tmp_path / "transfer.json"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(here, "dist_transfer_worker.py"), str(out),
+                        str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.load(open(out))
+    assert res["world"] == 2
+    for name in ("src", "t1", "t2"):
+        assert abs(res["perf"][name]["fooling_rate"] - float(z[f"{name}_fooling_rate"])) <= 1e-9, name
+        assert abs(res["perf"][name]["rmse"] - float(z[f"{name}_rmse"])) <= 1e-6
+        assert abs(res["perf"][name]["mse"] - float(z[f"{name}_mse"])) <= 1e-3
+
+
+def test_transfer_evaluation_all_six_reference_targets(tmp_path):
+    """configs[3] at plumbing scale: ONE dictionary, adversaries from DDrague against the source net, scored on all six
+    classifiers of the reference CLI (demo_dL_attack.py:41-53; random-init definitions from zoo, 224x224 inputs) through
+    performance.get_transfer_performance.  Checks the result layout and the metric identities (no golden: the reference
+    cannot build these networks offline)."""
+    import performance as perf
+    from attacks import ADIL
+    from dl_attack_on_imagenet_amd import zoo
+    names = ("resnet", "densenet", "googlenet", "inception", "mobilenet", "vgg")
+    models = {n: zoo.build_classifier(n, seed=3, device=DEV) for n in names}
+    g = torch.Generator().manual_seed(11)
+    images = torch.rand(8, 3, 224, 224, generator=g)
+    labels = models["resnet"](images.to(DEV)).argmax(-1).cpu()
+    d = -1 + 2 * torch.rand(3, 224, 224, 10, generator=g)
+    torch.save([d, torch.zeros(1), [], [], torch.tensor(0.)], os.path.join(tmp_path, "ImageNet_resnet.bin"))
+    atk = ADIL(models["resnet"], eps=8 / 255, n_atoms=10, attack="supervised", model_name="resnet", loss="logits",
+               steps_inference=4, dict_dir=str(tmp_path))
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(images, labels), batch_size=4, shuffle=False)
+    out = perf.get_transfer_performance({"adil": [atk]}, models, loader, device=torch.device(DEV))["adil"]
+    assert set(out) == set(names)
+    rm = [out[n]["rmse"] for n in names]
+    assert max(rm) - min(rm) < 1e-9 and 0 < rm[0] < 0.05          # one adversary, the same distortion for every target
+    for n in names:
+        assert 0.0 <= out[n]["fooling_rate"] <= 1.0 and np.isfinite(out[n]["mse"])
+    assert out["resnet"]["fooling_rate"] >= max(out[n]["fooling_rate"] for n in names if n != "resnet") - 0.25
