@@ -23,12 +23,13 @@ SIGNATURES = {
     "adil_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                           c_size_t, c_void_p]),
     "adil_adamw_clamp": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,
-                                 c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+                                 c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "adil_zstep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
                            c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_float, c_void_p,
                            c_void_p]),
     "adil_adamw_l1ball": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
-                                  c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+                                  c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                  c_void_p]),
     "adil_l1ball_project": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     "adil_l2ball_project": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     "adil_ista_step": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p]),
@@ -56,7 +57,7 @@ SIGNATURES = {
                                    c_void_p]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

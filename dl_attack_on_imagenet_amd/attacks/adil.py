@@ -62,6 +62,8 @@ class ADIL(Attack):
       stream_dtype   torch.float32 (default) or torch.bfloat16 for the image-shaped streams x+Dv and dLoss/dx
       dict_dir       folder of the dictionary file (default 'trained_dicts')
       shuffle_seed   seed of the per-epoch global batches of the data-parallel learner (identical on every rank)
+      use_graph      replay the learning step as one hipGraph launch (engine.DictionaryLearner.step_graphed): for
+                     launch-bound configurations (small batches / small classifiers); default: $ADIL_GRAPH == "1"
     """
 
     _learner_cls = engine.DictionaryLearner      # the fused (D, V) update; tests of the host logic may inject another
@@ -70,7 +72,7 @@ class ADIL(Attack):
                  data_train=None, data_val=None, trials=10, attack='supervised', model_name=None, step_size=0.01,
                  is_distributed=False, steps_in=None, loss='ce', method='gd', warm_start=False, kappa=50,
                  steps_inference=30, alpha=None, init_d=None, init_v=None, epoch_batches=None, val_batches=None,
-                 stream_dtype=None, dict_dir='trained_dicts', shuffle_seed=0):
+                 stream_dtype=None, dict_dir='trained_dicts', shuffle_seed=0, use_graph=None):
         super().__init__("ADIL", model.eval())
         self.norm = norm.lower()
         self.eps = eps
@@ -92,6 +94,7 @@ class ADIL(Attack):
         self._init_d, self._init_v = init_d, init_v
         self._epoch_batches, self._val_batches = epoch_batches, val_batches
         self._shuffle_seed = int(shuffle_seed)
+        self._use_graph = (os.environ.get("ADIL_GRAPH") == "1") if use_graph is None else bool(use_graph)
         self._pinv = None
         self._dict_mtime = None
         self.model_file = os.path.join(dict_dir, f"ImageNet_{model_name}.bin")
@@ -186,7 +189,7 @@ class ADIL(Attack):
             loss_full = torch.zeros((), dtype=torch.float32, device=self.device)
             fooled = torch.zeros((), dtype=torch.int64, device=self.device)
             for index, x in train.batches(self._epoch_order(n_img, batch_size, self._epoch_batches, iteration)):
-                ls, fl = learner.step(self.model, x, index)                                # adil.py:168-191
+                ls, fl = (learner.step_graphed if self._use_graph else learner.step)(self.model, x, index)   # adil.py:168-191
                 loss_full += ls
                 fooled += fl
             loss_all.append(loss_full.item() / n_img)                                      # adil.py:194

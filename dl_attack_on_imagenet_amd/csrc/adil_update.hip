@@ -7,7 +7,9 @@
 template <typename GT>
 __global__ __launch_bounds__(256) void adamw_clamp_kernel(float* __restrict__ p, const GT* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ s, size_t n,
-                                                          AdamWHyper h, float lo, float hi, float* max_abs_delta) {
+                                                          AdamWHyper h, float lo, float hi, float* max_abs_delta,
+                                                          const float* __restrict__ dyn) {
+    if (dyn != nullptr) { h.step_size = dyn[0]; h.bc2_sqrt = dyn[1]; }   // step-dependent scalars from device memory (graphs)
     const size_t n4 = n / 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     float local_max = 0.0f;
@@ -109,7 +111,9 @@ __global__ __launch_bounds__(256) void adamw_l1ball_kernel(float* __restrict__ v
                                                            float* __restrict__ s, int N, int K, AdamWHyper h,
                                                            float radius, float* max_abs_delta, int do_adam,
                                                            int reset_pos, const float* skip_if_below,
-                                                           float skip_threshold, float* clear) {
+                                                           float skip_threshold, float* clear,
+                                                           const float* __restrict__ dyn) {
+    if (dyn != nullptr) { h.step_size = dyn[0]; h.bc2_sqrt = dyn[1]; }   // step-dependent scalars from device memory (graphs)
     // device-side stop test of the solver loop (adil.py:614), see zstep_mfma_kernel
     if (skip_if_below != nullptr && *skip_if_below < skip_threshold) {
         if (max_abs_delta != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *max_abs_delta = 0.0f;   // stay stopped
@@ -401,7 +405,7 @@ static inline int stream_grid(size_t work_items, int per_block) {
     return (int)b;
 }
 
-extern "C" int adil_abi_version(void) { return 4; }
+extern "C" int adil_abi_version(void) { return 5; }
 extern "C" int adil_max_atoms(void) { return ADIL_MAX_ATOMS; }
 
 extern "C" int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, int32_t* pos,
@@ -453,7 +457,7 @@ extern "C" int adil_spd_inverse(const float* a, int K, float* out, void* stream)
 
 extern "C" int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, float* s, size_t n, float decay,
                                 float b1, float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi,
-                                float* max_abs_delta, void* stream) {
+                                float* max_abs_delta, const float* dyn_scalars, void* stream) {
     ADIL_ENTER();
     if (!p || !g || !m || !s || n == 0) return ADIL_EINVAL;
     if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)s | (uintptr_t)g) & 15) return ADIL_EINVAL;  // 16-B vector access
@@ -461,10 +465,10 @@ extern "C" int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, 
     const int grid = stream_grid(n / 4 + 1, 256);
     if (g_dtype == ADIL_F32)
         hipLaunchKernelGGL(adamw_clamp_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
-                           (const float*)g, m, s, n, h, lo, hi, max_abs_delta);
+                           (const float*)g, m, s, n, h, lo, hi, max_abs_delta, dyn_scalars);
     else if (g_dtype == ADIL_BF16)
         hipLaunchKernelGGL(adamw_clamp_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
-                           (const bf16_t*)g, m, s, n, h, lo, hi, max_abs_delta);
+                           (const bf16_t*)g, m, s, n, h, lo, hi, max_abs_delta, dyn_scalars);
     else
         return ADIL_EINVAL;
     ADIL_CHECK_LAUNCH();
@@ -474,14 +478,14 @@ extern "C" int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, 
 static int launch_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, float* m, float* s, int N, int K,
                                AdamWHyper h, float radius, float* max_abs_delta, int do_adam, int reset_pos,
                                hipStream_t st, const float* skip_if_below = nullptr, float skip_threshold = 0.0f,
-                               float* clear = nullptr) {
+                               float* clear = nullptr, const float* dyn = nullptr) {
     const dim3 grid((N + 3) / 4), block(256);
     if (K <= 64)
         hipLaunchKernelGGL(adamw_l1ball_kernel<1>, grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
-                           max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear);
+                           max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear, dyn);
     else
         hipLaunchKernelGGL(adamw_l1ball_kernel<2>, grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
-                           max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear);
+                           max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear, dyn);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
@@ -489,13 +493,13 @@ static int launch_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, flo
 extern "C" int adil_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, int reset_pos, float* m, float* s, int N,
                                  int K, float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt,
                                  float radius, float* max_abs_delta, const float* skip_if_below, float skip_threshold,
-                                 float* clear, void* stream) {
+                                 float* clear, const float* dyn_scalars, void* stream) {
     ADIL_ENTER();
     if (!v || !m || !s || N <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     if (!grad_vb && !pos) return ADIL_EINVAL;      // without a slot table every row reads its own gradient row
     AdamWHyper h{decay, b1, b2, eps, step_size, bc2_sqrt};
     return launch_adamw_l1ball(v, grad_vb, pos, m, s, N, K, h, radius, max_abs_delta, 1, reset_pos, (hipStream_t)stream,
-                               skip_if_below, skip_threshold, clear);
+                               skip_if_below, skip_threshold, clear, dyn_scalars);
 }
 
 extern "C" int adil_l1ball_project(float* x, int N, int K, float radius, void* stream) {

@@ -93,6 +93,9 @@ class DictionaryLearner:
         # configs[4]: the D.V contraction of the synthesis on fp8 MFMAs.  Legal here because every row of v lives in
         # the l1 ball of radius eps after update_v (so |v| <= eps bounds the code scale) and |d| <= 1 after update_d.
         self.fp8_absmax = float(eps) if fp8_synth else None
+        self._graph = None                       # (graph, x, index, loss, fooled, batch size) once `use_graph` captured a step
+        self._graph_warm = 0
+        self._dyn_d = self._dyn_v = None
 
     # -- pieces ------------------------------------------------------------- #
     def forward_backward(self, model, x: Tensor, index: Tensor, labels: Tensor, want_d: bool, want_v: bool):
@@ -121,14 +124,59 @@ class DictionaryLearner:
                 self.reducer.all_reduce_(gd)
         return zero, zero.to(torch.int64), gd, None
 
+    @staticmethod
+    def _next_scalars(sched, dyn):
+        """Advance the AdamW step counter.  With device-resident scalars (graphs) the two step-dependent values are copied
+        to the device first — except while a graph is being captured: the copy must stay OUTSIDE the graph (a recorded
+        host-to-device copy would re-read one fixed pinned slot on every replay); step_graphed issues it before replay."""
+        if dyn is None or torch.cuda.is_current_stream_capturing():
+            return sched.next()
+        return sched.next_to_device()
+
     def update_d(self, gd: Tensor) -> None:
-        ops.adamw_clamp_(self.d, gd, self.m_d, self.s_d, self.sched_d.next(), -1.0, 1.0)   # K4: step + update_d
+        h = self._next_scalars(self.sched_d, self._dyn_d)
+        ops.adamw_clamp_(self.d, gd, self.m_d, self.s_d, h, -1.0, 1.0, dyn=self._dyn_d)    # K4: step + update_d
 
     def update_v(self, gvb: Optional[Tensor]) -> None:
         if self.v.shape[0] == 0:
             return
-        ops.adamw_l1ball_(self.v, gvb, self.pos, self.m_v, self.s_v, self.sched_v.next(), self.eps,   # K5
-                          reset_pos=True)
+        h = self._next_scalars(self.sched_v, self._dyn_v)
+        ops.adamw_l1ball_(self.v, gvb, self.pos, self.m_v, self.s_v, h, self.eps, reset_pos=True,      # K5
+                          dyn=self._dyn_v)
+
+    # -- the whole step as ONE hipGraph launch (launch-bound configurations) ------------------------------------ #
+    def step_graphed(self, model, x: Tensor, index: Tensor):
+        """`step()` replayed from a hipGraph: the ~200 launches of a step (classifier forward twice, backward, the five
+        ADiL kernels) become one graph launch — what matters when the step is launch-bound (configs[0]: resnet18 on 32
+        images is ~15 ms eager for ~2 ms of kernel time).  The first two calls run eagerly (library autotuning must not
+        happen under capture), the third captures the step for this batch size and replays it; later calls copy x / index
+        into the graph's static inputs and replay.  AdamW's step-dependent scalars reach the recorded launches through
+        device memory (`dyn_scalars`).  A different batch size, a reducer (the collective is not captured) or an empty
+        batch falls back to the eager step.  Results are bit-identical to `step()` (tests/test_gpu_adil.py)."""
+        index = index.to(device=self.v.device, dtype=torch.int64)
+        b = x.shape[0]
+        if self.reducer is not None or b == 0 or (self._graph is not None and self._graph[5] != b):
+            return self.step(model, x, index)
+        if self._graph is None:
+            if self._graph_warm < 2:
+                self._graph_warm += 1
+                return self.step(model, x, index)
+            self._dyn_d = self.sched_d.enable_device_scalars(self.d.device)
+            self._dyn_v = self.sched_v.enable_device_scalars(self.v.device)
+            gx, gi = x.clone(), index.clone()
+            t_d, t_v = self.sched_d.t, self.sched_v.t
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                ls, fooled = self.step(model, gx, gi)
+            self.sched_d.t, self.sched_v.t = t_d, t_v            # capture records, it does not execute: no step was taken
+            self._graph = (graph, gx, gi, ls, fooled, b)
+        graph, gx, gi, ls, fooled, _ = self._graph
+        gx.copy_(x)
+        gi.copy_(index)
+        self.sched_d.next_to_device()                            # this step's scalars, ordered before the replay
+        self.sched_v.next_to_device()
+        graph.replay()
+        return ls.clone(), fooled.clone()
 
     # -- reference loops ---------------------------------------------------- #
     def step(self, model, x: Tensor, index: Tensor, labels: Optional[Tensor] = None):

@@ -94,6 +94,24 @@ class AdamWSchedule:
         bc2 = 1.0 - self.b2 ** self.t
         return AdamWScalars(1.0 - self.lr * self.wd, self.b1, self.b2, self.eps, self.lr / bc1, math.sqrt(bc2))
 
+    # -- hipGraph replay: the two step-dependent scalars live in device memory and are refreshed before each replay -- #
+    def enable_device_scalars(self, device) -> Tensor:
+        """A 2-float device buffer {step_size, bc2_sqrt} (the `dyn_scalars` of the AdamW entry points) fed through a ring
+        of pinned host slots, so that a launch recorded in a graph picks up the scalars of the step it is replayed for."""
+        self.dyn = torch.zeros(2, dtype=torch.float32, device=device)
+        self._pinned = torch.zeros(8, 2, dtype=torch.float32).pin_memory()
+        self._slot = 0
+        return self.dyn
+
+    def next_to_device(self) -> AdamWScalars:
+        """next(), and a stream-ordered copy of its step-dependent scalars into the device buffer."""
+        h = self.next()
+        slot = self._pinned[self._slot % 8]
+        self._slot += 1
+        slot[0], slot[1] = h.step_size, h.bc2_sqrt
+        self.dyn.copy_(slot, non_blocking=True)
+        return h
+
 
 class StopTest:
     """Device-side stop test of the inference solvers (`if max|x - x_old| < 1e-6: break`, adil.py:559, :614).
@@ -234,7 +252,7 @@ def grad(g: Tensor, d: Tensor, vp: Optional[Tensor], batch: int, *, want_d: bool
 
 
 def adamw_clamp_(p: Tensor, g: Tensor, m: Tensor, s: Tensor, h: AdamWScalars, lo: float, hi: float,
-                 max_abs_delta: Optional[Tensor] = None) -> None:
+                 max_abs_delta: Optional[Tensor] = None, dyn: Optional[Tensor] = None) -> None:
     """In-place fused AdamW + clamp[lo,hi] on a flat fp32 parameter (adil.py:186,188 / :554-555)."""
     lib = _lib.load()
     for name, t in (("p", p), ("m", m), ("s", s)):
@@ -246,7 +264,7 @@ def adamw_clamp_(p: Tensor, g: Tensor, m: Tensor, s: Tensor, h: AdamWScalars, lo
         _dev(max_abs_delta, "max_abs_delta", torch.float32)
     _lib.check(lib.adil_adamw_clamp(_ptr(p), _ptr(g), stream_dtype_code(g.dtype), _ptr(m), _ptr(s), p.numel(),
                                     h.decay, h.b1, h.b2, h.eps, h.step_size, h.bc2_sqrt, float(lo), float(hi),
-                                    _ptr(max_abs_delta), _stream()), "adil_adamw_clamp")
+                                    _ptr(max_abs_delta), _ptr(dyn), _stream()), "adil_adamw_clamp")
 
 
 def _stop_args(max_abs_delta: Optional[Tensor], stop: Optional[StopTest]):
@@ -275,7 +293,7 @@ def zstep_(z: Tensor, m: Tensor, s: Tensor, dpinv_t: Tensor, gvp: Tensor, batch:
 
 def adamw_l1ball_(v: Tensor, grad_vb: Optional[Tensor], pos: Optional[Tensor], m: Tensor, s: Tensor, h: AdamWScalars,
                   radius: float, max_abs_delta: Optional[Tensor] = None, reset_pos: bool = False,
-                  stop: Optional[StopTest] = None) -> None:
+                  stop: Optional[StopTest] = None, dyn: Optional[Tensor] = None) -> None:
     """In-place AdamW on ALL rows of v (zero gradient outside the batch) + l1-ball projection
     (adil.py:186-187; radius < 0 skips the projection).  pos is the batch-slot table written by pack_codes; with
     reset_pos the kernel hands it back all -1.  grad_vb None = no row of this v is in the batch (pos all -1)."""
@@ -298,7 +316,7 @@ def adamw_l1ball_(v: Tensor, grad_vb: Optional[Tensor], pos: Optional[Tensor], m
     dmax, skip, thr, clear = _stop_args(max_abs_delta, stop)
     _lib.check(lib.adil_adamw_l1ball(_ptr(v), _ptr(grad_vb), _ptr(pos), int(bool(reset_pos)), _ptr(m), _ptr(s), n, k,
                                      h.decay, h.b1, h.b2, h.eps, h.step_size, h.bc2_sqrt, float(radius),
-                                     dmax, skip, thr, clear, _stream()), "adil_adamw_l1ball")
+                                     dmax, skip, thr, clear, _ptr(dyn), _stream()), "adil_adamw_l1ball")
 
 
 def l1ball_project_(x: Tensor, radius: float) -> Tensor:

@@ -40,7 +40,8 @@ extern "C" {
 
 /* ABI version of this header; bumped on any signature change.  2: frozen-classifier entry points.  3: batch-slot table
  * written by adil_pack_codes and consumed + reset by adil_adamw_l1ball, adil_gather_images, adil_spd_inverse,
- * adil_synth_fp8.  4: device-side stop test arguments of adil_zstep / adil_adamw_l1ball. */
+ * adil_synth_fp8.  4: device-side stop test arguments of adil_zstep / adil_adamw_l1ball.  5: dyn_scalars of the two
+ * AdamW entry points (hipGraph replay of the learning step). */
 int adil_abi_version(void);
 
 /* Largest K (atoms) the kernels support. */
@@ -95,10 +96,13 @@ int adil_grad(const void* g, const float* d, const float* vp, float* grad_d, flo
  * double, exactly as torch does.  g has element type g_dtype.  If max_abs_delta != NULL,
  * atomically maxes |p_new - p_old| into it (a float the caller zeroed).
  * Replaces optimise.step() + update_d (adil.py:186,188 with :33-35; clamp [-1,1]) and
- * optimise.step() + the z clamp (adil.py:554-555, :559; clamp [-eps,eps]). */
+ * optimise.step() + the z clamp (adil.py:554-555, :559; clamp [-eps,eps]).
+ * dyn_scalars (optional, 2 device floats {step_size, bc2_sqrt}): when given they override the by-value arguments, so a
+ * launch recorded in a hipGraph can be replayed with the scalars of a later step (the caller refreshes the two floats with
+ * a stream-ordered copy before each replay). */
 int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, float* s, size_t n, float decay, float b1,
                      float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi,
-                     float* max_abs_delta, void* stream);
+                     float* max_abs_delta, const float* dyn_scalars, void* stream);
 
 /* Fused inference step of forward_supervised_DDrague (adil.py:551-559): the gradient wrt z,
  *     gz = gvp D_dagger   (gvp = packed dLoss/dv [Bp][Kp], dpinv_t = D_dagger^T stored P x K like D),
@@ -125,10 +129,11 @@ int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, const float* 
  * radius < 0 skips the projection.
  * Replaces optimise.step() + update_v (adil.py:186-187 with :29-31 and utils.py:21-41),
  * and the same pair in forward_supervised_AdamW (adil.py:609-610, :614); skip_if_below / skip_threshold / clear are the
- * device-side stop test described at adil_zstep (adil.py:614). */
+ * device-side stop test described at adil_zstep (adil.py:614); dyn_scalars as in adil_adamw_clamp. */
 int adil_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, int reset_pos, float* m, float* s, int N, int K,
                       float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt, float radius,
-                      float* max_abs_delta, const float* skip_if_below, float skip_threshold, float* clear, void* stream);
+                      float* max_abs_delta, const float* skip_if_below, float skip_threshold, float* clear,
+                      const float* dyn_scalars, void* stream);
 
 /* Row-wise Euclidean projection onto the l1 ball, in place: project_onto_l1_ball (utils.py:21-41). */
 int adil_l1ball_project(float* x, int N, int K, float radius, void* stream);

@@ -480,3 +480,29 @@ def test_transfer_evaluation_all_six_reference_targets(tmp_path):
     for n in names:
         assert 0.0 <= out[n]["fooling_rate"] <= 1.0 and np.isfinite(out[n]["mse"])
     assert out["resnet"]["fooling_rate"] >= max(out[n]["fooling_rate"] for n in names if n != "resnet") - 0.25
+
+
+def test_graphed_learner_step_is_bit_identical():
+    """DictionaryLearner.step_graphed (the whole step as one hipGraph launch, AdamW's step-dependent scalars through device
+    memory) against the eager step: full-batch and minibatch schedules incl. a ragged last batch (falls back to eager),
+    8 steps — D, V, both moment pairs, losses and fooled counts bit for bit."""
+    from dl_attack_on_imagenet_amd import engine, ops
+    from tinynet import make_tinynet
+    net = make_tinynet(4).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    images = torch.rand(20, 3, 32, 32, generator=g).to(DEV)
+    d0 = (-1 + 2 * torch.rand(3, 32, 32, 6, generator=g)).to(DEV)
+    v0 = ops.l1ball_project_(torch.rand(20, 6, generator=g).to(DEV), 0.3)
+    for schedule in ([list(range(20))] * 8,
+                     [[3, 1, 4, 15, 9, 2, 6, 5], [8, 7, 0, 19, 18, 17, 16, 14], [13, 12, 11, 10]] * 3):
+        a = engine.DictionaryLearner(d0.clone(), v0.clone(), 0.3, 0.01, "logits")
+        b = engine.DictionaryLearner(d0.clone(), v0.clone(), 0.3, 0.01, "logits")
+        for idx in schedule:
+            index = torch.tensor(idx, device=DEV)
+            la, fa = a.step(net, images[index].contiguous(), index)
+            lb, fb = b.step_graphed(net, images[index].contiguous(), index)
+            assert float(la) == float(lb) and int(fa) == int(fb)
+        assert b._graph is not None                                # a graph was captured and replayed
+        for x, y in ((a.d, b.d), (a.v, b.v), (a.m_d, b.m_d), (a.s_d, b.s_d), (a.m_v, b.m_v), (a.s_v, b.s_v)):
+            assert torch.equal(x, y)
+        assert a.sched_d.t == b.sched_d.t == len(schedule)
