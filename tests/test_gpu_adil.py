@@ -506,3 +506,43 @@ def test_graphed_learner_step_is_bit_identical():
         for x, y in ((a.d, b.d), (a.v, b.v), (a.m_d, b.m_d), (a.s_d, b.s_d), (a.m_v, b.m_v), (a.s_v, b.s_v)):
             assert torch.equal(x, y)
         assert a.sched_d.t == b.sched_d.t == len(schedule)
+
+
+def test_integration_md_stub_runs_a_learning_step():
+    """The ctypes stub printed in INTEGRATION.md is executed as it stands (only the library path is filled in) and drives
+    one learning step through the C ABI; the result equals the product's DictionaryLearner step bit for bit.  Keeps the
+    document honest about signatures and argument order."""
+    import re
+    from dl_attack_on_imagenet_amd import _lib, engine, ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    assert 'ctypes.CDLL("libadil_hip.so")' in code
+    ns = {}
+    exec(code.replace('ctypes.CDLL("libadil_hip.so")', f'ctypes.CDLL({_lib.LIBPATH!r})'), ns)
+    g = torch.Generator().manual_seed(13)
+    n, b, k, eps = 9, 6, 5, 0.4
+    x = torch.rand(b, 3, 16, 16, generator=g).to(DEV)
+    d0 = (-1 + 2 * torch.rand(3, 16, 16, k, generator=g)).to(DEV)
+    v0 = ops.l1ball_project_(torch.rand(n, k, generator=g).to(DEV), eps)
+    gup = torch.randn(b, 3, 16, 16, generator=g).to(DEV)                   # stands in for dLoss/d(x + Dv)
+    index = torch.tensor([4, 0, 8, 2, 7, 5], device=DEV)
+    # the stub, as a reference maintainer would call it (INTEGRATION.md section 3)
+    d, v = d0.clone(), v0.clone()
+    md, sd, mv, sv = torch.zeros_like(d), torch.zeros_like(d), torch.zeros_like(v), torch.zeros_like(v)
+    pos = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+    vp = ns["pack_codes"](v, index, pos)
+    xt = ns["synth"](x, d, vp)
+    gd, gv = ns["grad"](gup, d, vp)
+    scal = ns["adamw_scalars"](0.01, 1)
+    ns["adamw_clamp_"](d, gd, md, sd, scal, -1.0, 1.0)
+    ns["adamw_l1ball_"](v, gv, pos, mv, sv, scal, eps)
+    # the product
+    d2, v2 = d0.clone(), v0.clone()
+    vp2 = ops.pack_codes(v2, index, b)
+    assert torch.equal(xt, ops.synth(x, d2, vp2, b))
+    gd2, gv2 = ops.grad(gup, d2, vp2, b)
+    learner = engine.DictionaryLearner(d2, v2, eps, 0.01, "logits")
+    ops.pack_codes(learner.v, index, b, pos=learner.pos)
+    learner.update_d(gd2); learner.update_v(gv2)
+    assert torch.equal(d, learner.d) and torch.equal(v, learner.v) and int((pos != -1).sum()) == 0
