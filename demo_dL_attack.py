@@ -74,7 +74,10 @@ def main(args):
         torch.cuda.set_device(args.gpu)
         device = torch.device('cuda', args.gpu)
     else:
-        device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+        # one process per GPU (torchrun env); the process group also shards the evaluation below over the ranks
+        from dl_attack_on_imagenet_amd import dist as adist
+        _, _, local_rank = adist.init_from_env()
+        device = torch.device('cuda', adist.local_device_index(local_rank))
         torch.cuda.set_device(device)
 
     model_name = args.model.lower()          # names the dictionary file, as upstream (demo_dL_attack.py:41, adil.py:89-91)

@@ -63,7 +63,6 @@ template <> struct Mma<float> {
         r.l = __builtin_bit_cast(bf16x8, l);
         return r;
     }
-    static __device__ __forceinline__ Elem to_elem(float x) { return x; }
     static __device__ __forceinline__ void touch(Frag& f) {          // make the value opaque: its loads must have landed
         u32x4 h = __builtin_bit_cast(u32x4, f.h), m = __builtin_bit_cast(u32x4, f.m), l = __builtin_bit_cast(u32x4, f.l);
         asm volatile("" : "+v"(h), "+v"(m), "+v"(l));
@@ -103,7 +102,6 @@ template <> struct Mma<bf16_t> {
         for (int j = 0; j < 4; ++j) t[j] = pack2_bf16(f[2 * j], f[2 * j + 1]);
         return __builtin_bit_cast(Frag, t);
     }
-    static __device__ __forceinline__ Elem to_elem(float x) { return f32_to_bf16(x); }
     static __device__ __forceinline__ void touch(Frag& f) {
         u32x4 t = __builtin_bit_cast(u32x4, f);
         asm volatile("" : "+v"(t));
@@ -336,22 +334,6 @@ template <> struct BufPx<bf16_t> {
     }
 };
 
-// 8 consecutive pixels of one row as an MFMA fragment (the A operand of grad_v)
-template <typename T, bool FAST>
-__device__ __forceinline__ typename Mma<T>::Frag load_frag8(const T* rowp, int px, int P) {
-    if constexpr (FAST) {
-        return Mma<T>::load8(reinterpret_cast<const typename Mma<T>::Elem*>(rowp + px));   // stream type == Elem type
-    } else {
-        float f[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int q = px + i;
-            f[i] = Elem<T>::load(rowp, q < P ? q : P - 1) * ((q < P) ? 1.0f : 0.0f);
-        }
-        return Mma<T>::from8(f);
-    }
-}
-
 // 8 consecutive fp32 values (16-B aligned, e.g. a row of the packed codes) as an MFMA fragment
 template <typename T>
 __device__ __forceinline__ typename Mma<T>::Frag frag_from_f32x8(const float* p, float scale = 1.0f) {
@@ -362,23 +344,6 @@ __device__ __forceinline__ typename Mma<T>::Frag frag_from_f32x8(const float* p,
         for (int j = 0; j < 8; ++j) f[j] *= scale;
     }
     return Mma<T>::from8(f);
-}
-
-// N (2 or 4) consecutive fp32 values -> LDS as ONE store of the staged element type (address N-element aligned)
-template <typename E, int N> __device__ __forceinline__ void lds_put(E* p, const float (&f)[N]);
-template <> __device__ __forceinline__ void lds_put<float, 4>(float* p, const float (&f)[4]) {
-    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
-}
-template <> __device__ __forceinline__ void lds_put<float, 2>(float* p, const float (&f)[2]) {
-    *reinterpret_cast<float2*>(p) = make_float2(f[0], f[1]);
-}
-template <> __device__ __forceinline__ void lds_put<bf16_t, 4>(bf16_t* p, const float (&f)[4]) {
-    u32x2 t;
-    t[0] = pack2_bf16(f[0], f[1]); t[1] = pack2_bf16(f[2], f[3]);
-    *reinterpret_cast<u32x2*>(p) = t;
-}
-template <> __device__ __forceinline__ void lds_put<bf16_t, 2>(bf16_t* p, const float (&f)[2]) {
-    *reinterpret_cast<unsigned*>(p) = pack2_bf16(f[0], f[1]);
 }
 
 // Workgroup barrier for LDS hand-offs that leaves global loads in flight.  __syncthreads() carries a workgroup-scope
