@@ -26,7 +26,7 @@ SIGNATURES = {
                                  c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "adil_zstep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
                            c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_float, c_void_p,
-                           c_void_p]),
+                           c_void_p, c_void_p]),
     "adil_adamw_l1ball": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
                                   c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                   c_void_p]),

@@ -62,8 +62,9 @@ class ADIL(Attack):
       stream_dtype   torch.float32 (default) or torch.bfloat16 for the image-shaped streams x+Dv and dLoss/dx
       dict_dir       folder of the dictionary file (default 'trained_dicts')
       shuffle_seed   seed of the per-epoch global batches of the data-parallel learner (identical on every rank)
-      use_graph      replay the learning step as one hipGraph launch (engine.DictionaryLearner.step_graphed): for
-                     launch-bound configurations (small batches / small classifiers); default: $ADIL_GRAPH == "1"
+      use_graph      replay the learning step (engine.DictionaryLearner.step_graphed) and the DDrague inference iterations
+                     (engine.DDragueSolver.run, three per launch) as hipGraph launches: for launch-bound uses — small
+                     batches, the one-image attack of main.py; default: $ADIL_GRAPH == "1"
     """
 
     _learner_cls = engine.DictionaryLearner      # the fused (D, V) update; tests of the host logic may inject another
@@ -96,6 +97,7 @@ class ADIL(Attack):
         self._shuffle_seed = int(shuffle_seed)
         self._use_graph = (os.environ.get("ADIL_GRAPH") == "1") if use_graph is None else bool(use_graph)
         self._pinv = None
+        self._solvers = {}
         self._dict_mtime = None
         self.model_file = os.path.join(dict_dir, f"ImageNet_{model_name}.bin")
 
@@ -343,11 +345,24 @@ class ADIL(Attack):
         return adv, dv_norm.tolist()
 
     def forward_supervised_DDrague(self, images, labels, d):
-        """Optimise z with the perturbation D D_dagger z (adil.py:508-567); the default inference."""
+        """Optimise z with the perturbation D D_dagger z (adil.py:508-567); the default inference.  With use_graph the
+        iterations are replayed from a hipGraph (three per launch) and the solver — buffers and graph — is kept per
+        batch shape, so every batch of an evaluation after the first reuses the recorded graph."""
         if self._pinv is None or self._pinv.d is not d:
             self._pinv = engine.PseudoInverse(d)
-        return engine.solve_ddrague(self.model, self._cast(images), d, self.eps, self.steps_inference, self.loss,
-                                    self.targeted, self.kappa, pinv=self._pinv)
+            self._solvers = {}
+        images = self._cast(images)
+        if not self._use_graph:
+            return engine.solve_ddrague(self.model, images, d, self.eps, self.steps_inference, self.loss,
+                                        self.targeted, self.kappa, pinv=self._pinv)
+        key = (tuple(images.shape), images.dtype)
+        solver = self._solvers.get(key)
+        if solver is None:
+            solver = self._solvers[key] = engine.DDragueSolver(self.model, images, d, self.eps, self.loss, self.targeted,
+                                                               self.kappa, pinv=self._pinv)
+        else:
+            solver.reset(images)
+        return solver.run(self.steps_inference, use_graph=True).result()[0]
 
     def forward_supervised_AdamW(self, images, labels, d, model='train'):
         """Optimise the codes with D fixed (adil.py:569-623). 'train' -> fooled count, else adversarial images."""

@@ -664,7 +664,8 @@ __global__ __launch_bounds__(256) void zstep_mfma_kernel(float* __restrict__ z, 
                                                          const float* __restrict__ vp, int B, int P, int K, int Kp,
                                                          AdamWHyper hy, float lo, float hi, float* max_abs_delta,
                                                          int tile0, const float* skip_if_below, float skip_threshold,
-                                                         float* clear) {
+                                                         float* clear, const float* __restrict__ dyn) {
+    if (dyn != nullptr) { hy.step_size = dyn[0]; hy.bc2_sqrt = dyn[1]; }   // step-dependent scalars from device memory (graphs)
     using M = Mma<float>;
     using Frag = M::Frag;
     using DI = DImg<float>;
@@ -1602,14 +1603,15 @@ extern "C" int adil_grad(const void* g, const float* d, const float* vp, float* 
 template <bool FAST>
 static int launch_zstep_range(float* z, float* m, float* sq, const float* d, const float* vp, int B, int P, int K,
                               AdamWHyper hy, float lo, float hi, float* max_abs_delta, int tile0, int ntiles,
-                              const float* skip_if_below, float skip_threshold, float* clear, hipStream_t st) {
+                              const float* skip_if_below, float skip_threshold, float* clear, const float* dyn,
+                              hipStream_t st) {
     if (ntiles <= 0) return 0;
     const int Kp = round_up(K, 16);
     const size_t lds = (size_t)DImg<float>::PLANES * SYNTH_TILE * (Kp + DPAD) * sizeof(bf16_t);
     int rc = set_lds((const void*)zstep_mfma_kernel<FAST>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((zstep_mfma_kernel<FAST>), dim3(ntiles), dim3(256), lds, st, z, m, sq, d, vp, B, P, K, Kp, hy, lo, hi,
-                       max_abs_delta, tile0, skip_if_below, skip_threshold, clear);
+                       max_abs_delta, tile0, skip_if_below, skip_threshold, clear, dyn);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
@@ -1617,7 +1619,7 @@ static int launch_zstep_range(float* z, float* m, float* sq, const float* d, con
 extern "C" int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, const float* gvp, int B, int P, int K,
                           float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi,
                           float* max_abs_delta, const float* skip_if_below, float skip_threshold, float* clear,
-                          void* stream) {
+                          const float* dyn_scalars, void* stream) {
     ADIL_ENTER();
     if (!z || !m || !s || !dpinv_t || !gvp || B <= 0 || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     AdamWHyper hy{decay, b1, b2, eps, step_size, bc2_sqrt};
@@ -1627,8 +1629,9 @@ extern "C" int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, co
     const int nfast = vec ? P / SYNTH_TILE : 0;
     // `clear` is written by the first launch only (tile0 == 0 exists in exactly one of the two ranges)
     int rc = launch_zstep_range<true>(z, m, s, dpinv_t, gvp, B, P, K, hy, lo, hi, max_abs_delta, 0, nfast, skip_if_below,
-                                      skip_threshold, nfast > 0 ? clear : nullptr, (hipStream_t)stream);
+                                      skip_threshold, nfast > 0 ? clear : nullptr, dyn_scalars, (hipStream_t)stream);
     if (rc) return rc;
     return launch_zstep_range<false>(z, m, s, dpinv_t, gvp, B, P, K, hy, lo, hi, max_abs_delta, nfast, ntiles - nfast,
-                                     skip_if_below, skip_threshold, nfast > 0 ? nullptr : clear, (hipStream_t)stream);
+                                     skip_if_below, skip_threshold, nfast > 0 ? nullptr : clear, dyn_scalars,
+                                     (hipStream_t)stream);
 }

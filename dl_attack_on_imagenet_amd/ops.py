@@ -134,6 +134,10 @@ class StopTest:
         self.t += 1
         return self._slot(t), self._slot(t + 2), self.threshold, self._slot(t + 1)
 
+    def reset(self) -> None:
+        self.slots.copy_(torch.tensor([0.0, 0.0, 3.0e38], dtype=torch.float32))
+        self.t = 0
+
     def converged(self) -> bool:
         """True once the last launched iteration (or an earlier one) moved nothing by the threshold or more."""
         return self.t > 0 and float(self.slots[(self.t - 1) % 3]) < self.threshold
@@ -278,7 +282,8 @@ def _stop_args(max_abs_delta: Optional[Tensor], stop: Optional[StopTest]):
 
 
 def zstep_(z: Tensor, m: Tensor, s: Tensor, dpinv_t: Tensor, gvp: Tensor, batch: int, h: AdamWScalars, lo: float,
-           hi: float, max_abs_delta: Optional[Tensor] = None, stop: Optional[StopTest] = None) -> None:
+           hi: float, max_abs_delta: Optional[Tensor] = None, stop: Optional[StopTest] = None,
+           dyn: Optional[Tensor] = None) -> None:
     """In-place fused DDrague step: gz = gvp D_dagger formed on the fly, AdamW(z), clamp, max|dz| (adil.py:551-559)."""
     lib = _lib.load()
     for name, t in (("z", z), ("m", m), ("s", s), ("dpinv_t", dpinv_t), ("gvp", gvp)):
@@ -288,7 +293,8 @@ def zstep_(z: Tensor, m: Tensor, s: Tensor, dpinv_t: Tensor, gvp: Tensor, batch:
         raise ValueError("zstep_: operand shapes do not match (B, P, K)")
     dmax, skip, thr, clear = _stop_args(max_abs_delta, stop)
     _lib.check(lib.adil_zstep(_ptr(z), _ptr(m), _ptr(s), _ptr(dpinv_t), _ptr(gvp), batch, p, k, h.decay, h.b1, h.b2, h.eps,
-                              h.step_size, h.bc2_sqrt, float(lo), float(hi), dmax, skip, thr, clear, _stream()), "adil_zstep")
+                              h.step_size, h.bc2_sqrt, float(lo), float(hi), dmax, skip, thr, clear, _ptr(dyn), _stream()),
+               "adil_zstep")
 
 
 def adamw_l1ball_(v: Tensor, grad_vb: Optional[Tensor], pos: Optional[Tensor], m: Tensor, s: Tensor, h: AdamWScalars,

@@ -40,8 +40,8 @@ extern "C" {
 
 /* ABI version of this header; bumped on any signature change.  2: frozen-classifier entry points.  3: batch-slot table
  * written by adil_pack_codes and consumed + reset by adil_adamw_l1ball, adil_gather_images, adil_spd_inverse,
- * adil_synth_fp8.  4: device-side stop test arguments of adil_zstep / adil_adamw_l1ball.  5: dyn_scalars of the two
- * AdamW entry points (hipGraph replay of the learning step). */
+ * adil_synth_fp8.  4: device-side stop test arguments of adil_zstep / adil_adamw_l1ball.  5: dyn_scalars of the AdamW
+ * entry points incl. adil_zstep (hipGraph replay of the learning step and of the inference iterations). */
 int adil_abi_version(void);
 
 /* Largest K (atoms) the kernels support. */
@@ -114,10 +114,10 @@ int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, float* s, s
  * as well); otherwise `clear` (a float) is set to 0.  With three floats
  * s[0..2] = {0, 0, +big} and iteration t passing max_abs_delta = &s[t%3], skip_if_below = &s[(t+2)%3], clear =
  * &s[(t+1)%3], every launch after the converged one is a no-op, so the host may read s[t%3] only every few iterations
- * and still end on exactly the iterate the reference breaks at. */
+ * and still end on exactly the iterate the reference breaks at.  dyn_scalars as in adil_adamw_clamp. */
 int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, const float* gvp, int B, int P, int K, float decay,
                float b1, float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi, float* max_abs_delta,
-               const float* skip_if_below, float skip_threshold, float* clear, void* stream);
+               const float* skip_if_below, float skip_threshold, float* clear, const float* dyn_scalars, void* stream);
 
 /* Fused AdamW step on ALL N rows of the code matrix + row-wise l1-ball projection.
  * The gradient is non-zero only for the rows of the current batch: pos[n] = b if row n is

@@ -34,6 +34,8 @@ def build_parser():
     p.add_argument('--synthetic', action='store_true', help='attack a seeded random image instead of a JPEG')
     p.add_argument('--image-size', type=int, default=224, help='side of the synthetic image (must match the dictionary)')
     p.add_argument('--figure', default='attack_samples.png')
+    p.add_argument('--graph', type=int, default=1,
+                   help='replay the inference iterations from a hipGraph (a one-image attack is launch-bound); 0 = eager')
     return p
 
 
@@ -50,7 +52,7 @@ def main(args):
     else:
         im = load_image(args.image)
     eps = 8 / 255
-    attack = ADIL(model, eps=eps, model_name=model_name)                                 # main.py:80
+    attack = ADIL(model, eps=eps, model_name=model_name, use_graph=bool(args.graph))     # main.py:80
     im = im.to(device)
     label = model(im.unsqueeze(0)).argmax(dim=-1)
     adversary = attack(im.unsqueeze(0), label)

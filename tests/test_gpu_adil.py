@@ -546,3 +546,35 @@ def test_integration_md_stub_runs_a_learning_step():
     ops.pack_codes(learner.v, index, b, pos=learner.pos)
     learner.update_d(gd2); learner.update_v(gv2)
     assert torch.equal(d, learner.d) and torch.equal(v, learner.v) and int((pos != -1).sum()) == 0
+
+
+def test_graphed_ddrague_is_bit_identical(tmp_path):
+    """forward_supervised_DDrague replayed from a hipGraph (three iterations per launch, AdamW scalars and the stop slots in
+    device memory) against the eager loop: same adversarial images bit for bit — for step counts around the group size,
+    for a second and third batch served by the SAME recorded graph (ADIL keeps the solver per batch shape), and when the
+    loop converges in the middle of a replayed group."""
+    from attacks import ADIL
+    from dl_attack_on_imagenet_amd import engine
+    from tinynet import make_tinynet
+    net = make_tinynet(6).to(DEV)
+    g = torch.Generator().manual_seed(17)
+    d = (-1 + 2 * torch.rand(3, 32, 32, 6, generator=g)).to(DEV)
+    batches = [torch.rand(5, 3, 32, 32, generator=g).to(DEV) for _ in range(3)]
+    for steps in (5, 6, 14, 30):
+        eager = engine.solve_ddrague(net, batches[0], d, 0.1, steps, "logits")
+        graphed = engine.solve_ddrague(net, batches[0], d, 0.1, steps, "logits", use_graph=True)
+        assert torch.equal(eager, graphed), steps
+    torch.save([d.cpu(), torch.zeros(1), [], [], torch.tensor(0.)], os.path.join(tmp_path, "ImageNet_gr.bin"))
+    kw = dict(eps=0.1, n_atoms=6, attack="supervised", model_name="gr", loss="logits", steps_inference=11, dict_dir=str(tmp_path))
+    a, b = ADIL(net, use_graph=False, **kw), ADIL(net, use_graph=True, **kw)
+    lab = torch.zeros(5, dtype=torch.long, device=DEV)
+    for x in batches:
+        assert torch.equal(a(x, lab), b(x, lab))
+    assert len(b._solvers) == 1 and next(iter(b._solvers.values()))._graph is not None
+    # convergence inside a replayed group: a zero dictionary direction makes every z-step a no-op from the start
+    flat = make_tinynet(6).to(DEV)
+    for p in flat.parameters():
+        p.data.zero_()                                                    # constant logits -> zero gradient -> max|dz| = 0
+    e = engine.DDragueSolver(flat, batches[0], d, 0.1, "ce").run(20)
+    gr = engine.DDragueSolver(flat, batches[0], d, 0.1, "ce").run(20, use_graph=True)
+    assert torch.equal(e.result()[0], gr.result()[0]) and gr.stop.converged() and e.iters <= 4 and gr.iters <= 6
