@@ -102,6 +102,15 @@ class DictGradReducer:
     def all_reduce_(self, grad_d: torch.Tensor) -> torch.Tensor:
         return all_reduce_(grad_d, dist.ReduceOp.SUM, self.group)
 
+    def all_reduce_start(self, grad_d: torch.Tensor):
+        """Start the step's collective and return a handle whose .wait() orders the CURRENT stream behind it (RCCL runs on
+        its own stream): the caller puts the work that does not need the reduced gradient — AdamW + projection of the code
+        rows — between start and wait.  The gloo rehearsal path reduces synchronously and returns None."""
+        if _staged(grad_d, self.group):
+            all_reduce_(grad_d, dist.ReduceOp.SUM, self.group)
+            return None
+        return dist.all_reduce(grad_d, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def sum_scalars(self, *values) -> List[float]:
         """Per-epoch bookkeeping (loss, fooled counts): mirrors dist.reduce at adil.py:418-419."""
         dev = values[0].device if isinstance(values[0], torch.Tensor) else torch.device("cpu")

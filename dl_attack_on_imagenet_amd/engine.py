@@ -109,8 +109,11 @@ class DictionaryLearner:
         fooled = (out.argmax(dim=-1) != labels).sum()                                    # adil.py:177
         gd, gvb = ops.grad(g, self.d, vp, b, want_d=want_d, want_v=want_v,                # K2 + K3, one pass over g
                            grad_d=self.grad_d if want_d else None)
+        self._pending = None
         if want_d and self.reducer is not None:
-            self.reducer.all_reduce_(gd)                                                 # the ONE collective per step
+            # the ONE collective per step, started here and waited for in update_d: the update of the code rows, which
+            # does not depend on the reduced gradient, runs while RCCL moves grad_d over xGMI on its own stream
+            self._pending = self.reducer.all_reduce_start(gd)
         return ls, fooled, gd, gvb
 
     def _empty_batch(self, x: Tensor, want_d: bool):
@@ -118,10 +121,11 @@ class DictionaryLearner:
         joins the step's all-reduce, so every rank issues the same collectives in the same order."""
         zero = torch.zeros((), dtype=torch.float32, device=self.d.device)
         gd = None
+        self._pending = None
         if want_d:
             gd = self.grad_d.zero_()
             if self.reducer is not None:
-                self.reducer.all_reduce_(gd)
+                self._pending = self.reducer.all_reduce_start(gd)
         return zero, zero.to(torch.int64), gd, None
 
     @staticmethod
@@ -134,6 +138,9 @@ class DictionaryLearner:
         return sched.next_to_device()
 
     def update_d(self, gd: Tensor) -> None:
+        if getattr(self, "_pending", None) is not None:
+            self._pending.wait()                                 # stream-ordered: the host does not block
+            self._pending = None
         h = self._next_scalars(self.sched_d, self._dyn_d)
         ops.adamw_clamp_(self.d, gd, self.m_d, self.s_d, h, -1.0, 1.0, dyn=self._dyn_d)    # K4: step + update_d
 
@@ -185,8 +192,8 @@ class DictionaryLearner:
         if labels is None and x.shape[0]:
             labels = predict(model, x)                                                   # adil.py:172
         ls, fooled, gd, gvb = self.forward_backward(model, x, index, labels, True, True)
+        self.update_v(gvb)                                       # overlaps with the all-reduce of grad_d (if any)
         self.update_d(gd)
-        self.update_v(gvb)
         return ls, fooled
 
     def step_codes(self, model, x: Tensor, index: Tensor, labels: Optional[Tensor] = None):
