@@ -1245,6 +1245,164 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
     }
 }
 
+// =========================================================================================================== //
+// Fused single pass for fp32 streams (aligned interior).  The generic kernel above, instantiated for fp32, is bound by
+// conversion work: every wave splits the fp32 image fragments it reads (row fragments for grad_v, column fragments
+// for grad_d) and re-expands the code fragments on every tile — 880 VALU per wave and 64-pixel tile next to 96
+// MFMAs (117 us per 256 rows against 50 + 56 us for the two single-output kernels).  Here every operand is split
+// ONCE: the g tile when it is copied to LDS (three bf16 planes, like the D tile), the codes before the loop (32-pixel
+// tiles need only four code fragments per wave, so their twelve-register split form fits).  All fragment loads are
+// then plain / transposed bf16 LDS reads, exactly as in the bf16 kernel, three planes each.  32-pixel tiles, two
+// tiles in flight in two register stages; 256 rows per launch (LDS: planes of 256 x 32 px = 60 KB + D 30 KB + 32 KB).
+// =========================================================================================================== //
+template <int AT, int NW, bool ACC>
+__global__ __launch_bounds__(NW * 64) void grad_fused_f32_kernel(const float* __restrict__ g, const float* __restrict__ d,
+                                                                 const float* __restrict__ vpt, int vstride,
+                                                                 float* __restrict__ grad_d, float* __restrict__ slab, int B,
+                                                                 int Bp, int P, int K, int ntiles, int tiles_per_wg) {
+    using M = Mma<float>;
+    using Frag = M::Frag;
+    constexpr int TW = 32, KA = AT * 32, NT = NW * 64;
+    constexpr int GI = TW + DPAD;                                // image plane row stride (bf16 elements): 5 x 16 B
+    constexpr int IPL = NW * 32 * GI;                            // one image plane: [NW*32 rows][GI]
+    constexpr int GD = TW + DPAD, DPL = KA * GD, DBUF = 3 * DPL; // D tile: three planes of [KA][GD]
+    constexpr int LPR = TW / 4, RPI = 64 / LPR, NLD = 32 / RPI;  // fp32 rows: 8 lanes x 16 B per row, 8 rows per load, 4 loads
+    constexpr int DPT = (TW * KA + NT - 1) / NT;
+    constexpr int NTILE = AT, KS = NW / NTILE, RS = NW * 32 / KS, NKG = RS / 16, RPW = 16 / KS;
+    static_assert(NW % NTILE == 0 && KS > 1 && 16 % KS == 0, "row splits must divide the 16 accumulator registers");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sdt = reinterpret_cast<bf16_t*>(smem_raw);           // [2][3][KA][GD]
+    bf16_t* simg = sdt + 2 * DBUF;                               // [3][NW*32][GI]
+    float* red = reinterpret_cast<float*>(simg + 3 * IPL);       // [NW][16][64]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    const int t0 = blockIdx.x * tiles_per_wg;
+    const int t1 = min(ntiles, t0 + tiles_per_wg);
+    const int ta = w % NTILE, ks = w / NTILE;
+    const int b0 = w * 32;
+    const bool active = b0 < Bp;
+    const int lrow = lane / LPR, lcol = (lane - lrow * LPR) * 4;
+
+    f32x16 accv[AT];
+#pragma unroll
+    for (int at = 0; at < AT; ++at)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accv[at][r] = 0.0f;
+
+    Frag vfr[NKG];                                               // codes of this wave's row split, split once
+#pragma unroll
+    for (int kg = 0; kg < NKG; ++kg) {
+        const int r0 = ks * RS + 16 * kg;
+        vfr[kg] = M::load8(vpt + (size_t)(ta * 32 + c) * vstride + ((r0 < Bp) ? r0 : 0) + 8 * h);
+    }
+#pragma unroll
+    for (int kg = 0; kg < NKG; ++kg) M::touch(vfr[kg]);          // retired before the loop (see the generic kernel)
+
+    struct Stage { float dreg[DPT]; u32x4 blk[NLD]; };
+    auto load_stage = [&](Stage& st, int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) {                           // raw loads, clamped addresses (masked when written)
+            const int i = tid + e * NT;
+            const int px = i / KA, a = i - px * KA;
+            st.dreg[e] = d[(size_t)(tile * TW + (px < TW ? px : TW - 1)) * K + (a < K ? a : K - 1)];
+        }
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int row = b0 + i * RPI + lrow;
+                st.blk[i] = *reinterpret_cast<const u32x4*>(g + (size_t)(row < B ? row : B - 1) * P + tile * TW + lcol);
+            }
+        }
+    };
+    auto write_d = [&](bf16_t* dst, const Stage& st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) {
+            const int i = tid + e * NT;
+            const int px = i / KA, a = i - px * KA;
+            if (px < TW) DImg<float>::put(dst, a * GD + px, DPL, st.dreg[e] * ((a < K) ? 1.0f : 0.0f));
+        }
+    };
+    Stage sa, sb;
+    if (t0 < t1) load_stage(sa, t0);
+    if (t0 + 1 < t1) load_stage(sb, t0 + 1);
+    if (t0 < t1) write_d(sdt, sa);
+
+    auto tile_step = [&](int tile, int dbuf, Stage& cur, Stage& oth) __attribute__((always_inline)) {
+        if (active) {                                             // this wave's 32 rows -> the three image planes
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const float f4[4] = {__uint_as_float(cur.blk[i][0]), __uint_as_float(cur.blk[i][1]),
+                                     __uint_as_float(cur.blk[i][2]), __uint_as_float(cur.blk[i][3])};
+                DImg<float>::put4(simg, (b0 + i * RPI + lrow) * GI + lcol, IPL, f4);
+            }
+        }
+        float dold[ACC ? RPW : 1];
+        if constexpr (ACC) {                                      // old grad_d of THIS tile, requested before the prefetch
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int atom = ta * 32 + c;
+                dold[rr] = grad_d[(size_t)(tile * TW + c_row(ks * RPW + rr, h)) * K + (atom < K ? atom : K - 1)];
+            }
+        }
+        if (tile + 2 < t1) load_stage(cur, tile + 2);
+        lds_barrier();                                          // all image planes + D[dbuf] visible
+        if (active) {                                             // ---- grad_v: rows of this wave, all 32 pixels
+            const bf16_t* sdb = sdt + dbuf * DBUF;
+#pragma unroll
+            for (int g3 = 0; g3 < TW / 16; ++g3) {
+                const Frag a = DImg<float>::load8(simg + (b0 + c) * GI + 16 * g3 + 8 * h, IPL);
+#pragma unroll
+                for (int at = 0; at < AT; ++at)
+                    M::mma(accv[at], a, DImg<float>::load8(sdb + (at * 32 + c) * GD + 16 * g3 + 8 * h, DPL));
+            }
+        }
+        f32x16 accd;                                              // ---- grad_d: atom tile ta, rows ks*RS .. +RS
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accd[r] = 0.0f;
+#pragma unroll
+        for (int kg = 0; kg < NKG; ++kg) {
+            const int r0 = ks * RS + 16 * kg;
+            if (Bp == NW * 32 || r0 < Bp) {                       // wave-uniform
+                Frag a;
+                a.h = ColFrag<bf16_t>::load(simg + (size_t)(r0 & ~31) * GI, GI, r0 & 16, 0, lane);
+                a.m = ColFrag<bf16_t>::load(simg + IPL + (size_t)(r0 & ~31) * GI, GI, r0 & 16, 0, lane);
+                a.l = ColFrag<bf16_t>::load(simg + 2 * IPL + (size_t)(r0 & ~31) * GI, GI, r0 & 16, 0, lane);
+                M::mma(accd, a, vfr[kg]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(w * 16 + r) * 64 + lane] = accd[r];
+        lds_barrier();                                          // partials visible; all image and D[dbuf] reads done
+        {
+            const int atom = ta * 32 + c;
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int reg = ks * RPW + rr;
+                float sum = 0.0f;
+#pragma unroll
+                for (int q = 0; q < KS; ++q) sum += red[((ta + NTILE * q) * 16 + reg) * 64 + lane];
+                if (atom < K) {
+                    float* o = grad_d + (size_t)(tile * TW + c_row(reg, h)) * K + atom;
+                    if constexpr (ACC) *o = dold[rr] + sum; else *o = sum;
+                }
+            }
+        }
+        if (tile + 1 < t1) write_d(sdt + (dbuf ^ 1) * DBUF, oth);
+    };
+    for (int tile = t0; tile < t1; tile += 2) {
+        tile_step(tile, 0, sa, sb);
+        if (tile + 1 < t1) tile_step(tile + 1, 1, sb, sa);
+    }
+    if (active) {
+        float* dst = slab + (size_t)blockIdx.x * Bp * K;
+#pragma unroll
+        for (int at = 0; at < AT; ++at)
+            if (at * 32 + c < K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(size_t)(b0 + c_row(r, h)) * K + at * 32 + c] = accv[at][r];
+            }
+    }
+}
+
 // codes transposed + converted to the MFMA element type: vpt[a][b] = vp[b][a]  (a < KA, b < Bp)
 template <typename E>
 __global__ __launch_bounds__(256) void transpose_codes_kernel(const float* __restrict__ vp, int Bp, int Kp, int KA,
@@ -1538,6 +1696,34 @@ static int launch_grad_fused(const T* g, const float* d, const float* vp, float*
     const int tpw_slow = nslow > 0 ? (nslow + kNumCU - 1) / kNumCU : 1;
     const int nwg_slow = nslow > 0 ? (nslow + tpw_slow - 1) / tpw_slow : 0;
     const int chunk = FusedCfg<T, AT>::kMaxRows;
+    if constexpr (sizeof(T) == 4 && AT <= 2) {
+        // fp32 streams, aligned rows, whole 32-pixel tiles: every operand split once (grad_fused_f32_kernel)
+        if (vec && P % 32 == 0) {
+            constexpr int NW = 8, TW = 32;
+            const int nt = P / TW, tpw = (nt + kNumCU - 1) / kNumCU, nwg = (nt + tpw - 1) / tpw;
+            const size_t lds = (2 * 3 * (size_t)KA * (TW + DPAD) + 3 * (size_t)NW * 32 * (TW + DPAD)) * sizeof(bf16_t) +
+                               (size_t)NW * 16 * 64 * sizeof(float);
+            int rc = set_lds((const void*)grad_fused_f32_kernel<AT, NW, false>, lds);
+            if (rc) return rc;
+            rc = set_lds((const void*)grad_fused_f32_kernel<AT, NW, true>, lds);
+            if (rc) return rc;
+            for (int r0 = 0; r0 < Bp; r0 += NW * 32) {
+                const int rows_p = imin(Bp - r0, NW * 32), rows = imin(B - r0, rows_p);
+                const float* gc = (const float*)g + (size_t)r0 * P;
+                if (accumulate_d || r0 > 0)
+                    hipLaunchKernelGGL((grad_fused_f32_kernel<AT, NW, true>), dim3(nwg), dim3(NW * 64), lds, st, gc, d,
+                                       (const float*)vpt + r0, Bp, grad_d, slab, rows, rows_p, P, K, nt, tpw);
+                else
+                    hipLaunchKernelGGL((grad_fused_f32_kernel<AT, NW, false>), dim3(nwg), dim3(NW * 64), lds, st, gc, d,
+                                       (const float*)vpt + r0, Bp, grad_d, slab, rows, rows_p, P, K, nt, tpw);
+                ADIL_CHECK_LAUNCH();
+                hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows_p * K + 63) / 64), dim3(256), 0, st, (const float*)slab,
+                                   nwg, rows_p, K, rows, K, grad_vb + (size_t)r0 * K);
+                ADIL_CHECK_LAUNCH();
+            }
+            return 0;
+        }
+    }
     for (int r0 = 0; r0 < Bp; r0 += chunk) {
         const int rows_p = imin(Bp - r0, chunk), rows = imin(B - r0, rows_p);
         const T* gc = g + (size_t)r0 * P;

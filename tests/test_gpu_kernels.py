@@ -601,3 +601,30 @@ def test_grad_fused_whole_workgroups(b, k, hw):
     acc = gd.clone()
     ops().grad(g, d, vp, b, want_v=True, grad_d=acc, accumulate_d=True)
     close(acc, 2 * gd, 2e-6 * b ** 0.5 * 8)
+
+
+@pytest.mark.parametrize("b,k,hw", [(256, 50, 64), (512, 50, 64), (500, 10, 64), (70, 64, 32), (33, 33, 16), (300, 50, 224)])
+def test_grad_fused_fp32_presplit_kernel(b, k, hw):
+    """The fp32 fused pass with every operand split once (grad_fused_f32_kernel: 32-pixel tiles, image and dictionary
+    planes in LDS, pre-split codes): one launch and an accumulating second chunk (512 / 500 / 300 rows), ragged rows,
+    one / a few / many tiles per workgroup, both atom-tile counts — against fp64 matmuls at fp32-grade tolerances,
+    against the two single-output kernels, accumulation into an existing grad_d, bitwise reproducible."""
+    gen = torch.Generator().manual_seed(b + k + hw + 1)
+    d = (-1 + 2 * torch.rand(3, hw, hw, k, generator=gen)).to(DEV)
+    v = (torch.randn(b, k, generator=gen) * 0.02).to(DEV)
+    g = torch.randn(b, 3, hw, hw, generator=gen).to(DEV)
+    vp = ops().pack_codes(v, None, b)
+    gd, gvb = ops().grad(g, d, vp, b)
+    p = 3 * hw * hw
+    g2 = g.double().reshape(b, -1)
+    close(gd.reshape(-1, k), g2.t() @ v.double(), 2e-6 * b ** 0.5 * 4)
+    close(gvb, g2 @ d.double().reshape(-1, k), 3e-6 * p ** 0.5 * 4)
+    gd_only, _ = ops().grad(g, d, vp, b, want_v=False)
+    _, gv_only = ops().grad(g, d, None, b, want_d=False)
+    close(gd, gd_only, 2e-6 * b ** 0.5 * 4)
+    close(gvb, gv_only, 3e-6 * p ** 0.5 * 4)
+    gd2, gvb2 = ops().grad(g, d, vp, b)
+    assert torch.equal(gd, gd2) and torch.equal(gvb, gvb2)
+    acc = gd.clone()
+    ops().grad(g, d, vp, b, grad_d=acc, accumulate_d=True)
+    close(acc, 2 * gd, 2e-6 * b ** 0.5 * 8)
