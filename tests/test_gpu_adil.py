@@ -578,3 +578,23 @@ def test_graphed_ddrague_is_bit_identical(tmp_path):
     e = engine.DDragueSolver(flat, batches[0], d, 0.1, "ce").run(20)
     gr = engine.DDragueSolver(flat, batches[0], d, 0.1, "ce").run(20, use_graph=True)
     assert torch.equal(e.result()[0], gr.result()[0]) and gr.stop.converged() and e.iters <= 4 and gr.iters <= 6
+
+
+@pytest.mark.parametrize("graph", [1, 0])
+def test_main_cli_one_image_attack(graph, tmp_path, monkeypatch):
+    """main.py end to end (the reference's one-image demo, main.py:29-100): default classifier (mobilenet_v2), the
+    dictionary file named after the CLI's model string, 30 DDrague iterations — with the hipGraph replay main.py uses by
+    default and with the eager loop; both must report the same labels."""
+    import main as main_cli
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("trained_dicts")
+    g = torch.Generator().manual_seed(3)
+    torch.save([-1 + 2 * torch.rand(3, 224, 224, 100, generator=g), torch.zeros(1), [], [], torch.tensor(0.)],
+               "trained_dicts/ImageNet_mobilenet.bin")
+    args = main_cli.build_parser().parse_args(["--synthetic", "--graph", str(graph), "--figure", str(tmp_path / "fig.png")])
+    out = main_cli.main(args)
+    assert isinstance(out, tuple) and len(out) == 2 and all(isinstance(v, int) for v in out)
+    test_main_cli_one_image_attack.seen = getattr(test_main_cli_one_image_attack, "seen", {})
+    test_main_cli_one_image_attack.seen[graph] = out
+    if len(test_main_cli_one_image_attack.seen) == 2:
+        assert test_main_cli_one_image_attack.seen[0] == test_main_cli_one_image_attack.seen[1]
