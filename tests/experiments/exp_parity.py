@@ -1,6 +1,6 @@
 """Experiment: where does the config-1 D mismatch come from? CPU-oracle vs GPU-oracle (same code on cuda tensors) vs HIP."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dl_attack_on_imagenet_amd import engine, zoo
 from oracle import adil_oracle as O

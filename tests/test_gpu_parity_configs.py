@@ -77,7 +77,7 @@ def test_config1_same_backend_fooled_counts_exact():
         <= 2.5e-3, max |D v_hip - D v_oracle| <= 1e-2 (budget eps = 0.0314).  The fraction of dictionary entries ending
         more than 1e-3 apart is REPORTED, not bounded: AdamW's update is ~lr*sign(g) wherever |g| is small, so an entry
         whose gradient sign differs in the last bit moves 2*lr apart and never meets again (0.35 here; oracle-CPU vs
-        oracle-GPU shows the same, tools/exp_parity.py -> profiles/r02_exp_parity.txt).
+        oracle-GPU shows the same, tests/experiments/exp_parity.py -> profiles/r02_parity_configs.md).
     (2) TEACHER-FORCED, which is what isolates the kernels: before every one of the 20 iterations the HIP learner is
         put into the oracle's exact state (D, V, both AdamW moment pairs, step counters), both take ONE step, and the
         results must agree tightly at every point of the real trajectory: |dD| median <= 1e-6, entries off by more
