@@ -283,3 +283,24 @@ def test_vit_patch_embedding_is_the_convolution():
     (ga,) = torch.autograd.grad((a * w).sum(), x)
     (gb,) = torch.autograd.grad((b * w).sum(), x)
     assert float((ga - gb).abs().max()) < 1e-5
+
+
+def test_main_load_image_follows_the_reference_transform(tmp_path):
+    """main.load_image = Resize(256) / CenterCrop(224) / ToTensor of the reference (main.py:64-75, DS_ImageNet.py:14-18)
+    without torchvision: shorter side to 256 (bilinear), central 224 x 224 crop, float CHW in [0, 1]."""
+    PIL = pytest.importorskip("PIL.Image")
+    import numpy as np
+    import main as main_cli
+    rng = np.random.default_rng(0)
+    arr = rng.integers(0, 256, size=(300, 480, 3), dtype=np.uint8)           # H=300, W=480
+    path = tmp_path / "img.png"
+    PIL.fromarray(arr).save(path)
+    x = main_cli.load_image(str(path))
+    assert x.shape == (3, 224, 224) and x.dtype == torch.float32 and 0.0 <= float(x.min()) and float(x.max()) <= 1.0
+    im = PIL.open(path).convert("RGB").resize((round(480 * 256 / 300), 256), PIL.BILINEAR)   # (410, 256)
+    left, top = (im.size[0] - 224) // 2, (256 - 224) // 2
+    want = torch.from_numpy(np.asarray(im.crop((left, top, left + 224, top + 224)), dtype=np.float32) / 255).permute(2, 0, 1)
+    assert torch.equal(x, want)
+    # a portrait image: the WIDTH becomes 256
+    PIL.fromarray(arr.transpose(1, 0, 2)).save(path)
+    assert main_cli.load_image(str(path)).shape == (3, 224, 224)
