@@ -407,11 +407,12 @@ def attack_unsupervised(model, images: Tensor, d: Tensor, eps: float, v_trials: 
     mse_best_no_fool = torch.full((b,), float("inf"), device=dev)
     adv_best = images.clone()
     dv_norm_inf = None
-    for vt in v_trials:
+    for trial, vt in enumerate(v_trials):
         vp = ops.pack_codes(vt.to(device=dev, dtype=torch.float32).contiguous(), None, b)
         adv = ops.synth(images, d, vp, b, delta_clamp=eps, pixel_clamp=True)             # adil.py:481-484
-        dv = ops.synth(None, d, vp, b, out_shape=images.shape, out_dtype=torch.float32, delta_clamp=eps)
-        dv_norm_inf = dv.abs().flatten(1).max(dim=1).values
+        if trial == len(v_trials) - 1:           # only the LAST trial's norms are returned (quirk Q12): one extra launch, once
+            dv = ops.synth(None, d, vp, b, out_shape=images.shape, out_dtype=torch.float32, delta_clamp=eps)
+            dv_norm_inf = dv.abs().flatten(1).max(dim=1).values
         fooling = predict(model, adv) != pre
         mse, _ = ops.image_metrics(adv, images)
         # keep-best bookkeeping of adil.py:494-504, vectorised
