@@ -1749,12 +1749,13 @@ static int launch_grad_cfg(const T* g, const float* d, const float* vp, float* g
     float* slab = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + (((size_t)KA * Bp * sizeof(float) + 255) / 256) * 256);
     int rc = 0;
     if constexpr (FusedCfg<T, AT>::kMaxRows > 0) {                 // learning step: both outputs from ONE pass over g
-        // ... while the batch fits two fused launches.  Every row chunk after the first has to ACCUMULATE into grad_d (the
+        // ... while the batch fits four fused launches.  Every row chunk after the first has to ACCUMULATE into grad_d (the
         // ACC variant: old tile values requested before the next tile's loads so that waiting for them does not drain the
         // prefetch).  Measured, fused chunks vs the two single-output kernels: bf16 1024 rows K=50 (2 chunks) 128 vs 198 us;
-        // fp32 512 rows K=50 (2 chunks) 233 vs 242 us; bf16 1024 rows K=100 (4 chunks) 345 vs 295 us (before ACC).
+        // fp32 512 rows K=50 (2 chunks) 233 vs 242 us; bf16 2048 rows K=50 (4 chunks) 248 vs 360 us; bf16 1024 rows K=100
+        // (4 chunks) 291.5 vs 291.3 us; 768 rows K=100 (3 chunks) 214 vs 234 us.
         constexpr int kRows = FusedCfg<T, AT>::kMaxRows;
-        const bool fused = Bp <= 2 * kRows;
+        const bool fused = Bp <= 4 * kRows;
         if (grad_d != nullptr && grad_vb != nullptr && fused)
             return launch_grad_fused<T, AT>(g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, slab, st);
     }
