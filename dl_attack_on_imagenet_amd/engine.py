@@ -96,6 +96,7 @@ class DictionaryLearner:
         self._graph = None                       # (graph, x, index, loss, fooled, batch size) once `use_graph` captured a step
         self._graph_warm = 0
         self._dyn_d = self._dyn_v = None
+        self._pending = None                     # handle of the step's all-reduce between forward_backward and update_d
 
     # -- pieces ------------------------------------------------------------- #
     def forward_backward(self, model, x: Tensor, index: Tensor, labels: Tensor, want_d: bool, want_v: bool):
@@ -138,7 +139,7 @@ class DictionaryLearner:
         return sched.next_to_device()
 
     def update_d(self, gd: Tensor) -> None:
-        if getattr(self, "_pending", None) is not None:
+        if self._pending is not None:
             self._pending.wait()                                 # stream-ordered: the host does not block
             self._pending = None
         h = self._next_scalars(self.sched_d, self._dyn_d)
@@ -154,8 +155,8 @@ class DictionaryLearner:
     # -- the whole step as ONE hipGraph launch (launch-bound configurations) ------------------------------------ #
     def step_graphed(self, model, x: Tensor, index: Tensor):
         """`step()` replayed from a hipGraph: the ~200 launches of a step (classifier forward twice, backward, the five
-        ADiL kernels) become one graph launch — what matters when the step is launch-bound (configs[0]: resnet18 on 32
-        images is ~15 ms eager for ~2 ms of kernel time).  The first two calls run eagerly (library autotuning must not
+        ADiL kernels) become one graph launch — for launch-bound uses (small crops, tiny classifiers; configs[0] itself,
+        resnet18 on 32 images of 224x224, turned out GPU-bound: 7.2 ms either way).  The first two calls run eagerly (library autotuning must not
         happen under capture), the third captures the step for this batch size and replays it; later calls copy x / index
         into the graph's static inputs and replay.  AdamW's step-dependent scalars reach the recorded launches through
         device memory (`dyn_scalars`).  A different batch size, a reducer (the collective is not captured) or an empty
