@@ -1403,6 +1403,107 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_f32_kernel(const float* __
     }
 }
 
+// =========================================================================================================== //
+// grad_v for fp32 streams (aligned interior): the forward contraction v = z D_dagger^T of the DDrague iteration (fp32 z)
+// and dL/dv = g D of the fp32 parity path.  Same idea as grad_fused_f32_kernel: the stream operand is split into its
+// three bf16 planes ONCE, when the wave copies its 32 x 32-pixel block to LDS (the generic kernel splits every fragment
+// at load time and fits only 256 rows per launch); with 32-pixel tiles the planes of 512 rows fit (120 KB + 30 KB of D
+// planes), so the whole batch is one launch: D_dagger read once, one slab per workgroup.  A wave only ever reads its own
+// rows of the image, so the single barrier per tile is for the shared D tile.  Two tiles in flight in two register stages.
+// =========================================================================================================== //
+template <int AT, int NW>
+__global__ __launch_bounds__(NW * 64) void grad_v_f32_kernel(const float* __restrict__ g, const float* __restrict__ d,
+                                                             float* __restrict__ slab, int B, int Bp, int P, int K, int ntiles,
+                                                             int tiles_per_wg) {
+    using M = Mma<float>;
+    using Frag = M::Frag;
+    constexpr int TW = 32, KA = AT * 32, NT = NW * 64;
+    constexpr int GI = TW + DPAD, IPL = NW * 32 * GI;            // image planes [3][NW*32][GI]
+    constexpr int GD = TW + DPAD, DPL = KA * GD, DBUF = 3 * DPL; // D tile planes [2][3][KA][GD]
+    constexpr int LPR = TW / 4, RPI = 64 / LPR, NLD = 32 / RPI;
+    constexpr int DPT = (TW * KA + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sdt = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* simg = sdt + 2 * DBUF;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    const int t0 = blockIdx.x * tiles_per_wg;
+    const int t1 = min(ntiles, t0 + tiles_per_wg);
+    const int b0 = w * 32;
+    const bool active = b0 < Bp;                                 // waves beyond the batch only help staging D
+    const int lrow = lane / LPR, lcol = (lane - lrow * LPR) * 4;
+    f32x16 accv[AT];
+#pragma unroll
+    for (int at = 0; at < AT; ++at)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accv[at][r] = 0.0f;
+
+    struct Stage { float dreg[DPT]; u32x4 blk[NLD]; };
+    auto load_stage = [&](Stage& st, int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) {
+            const int i = tid + e * NT;
+            const int px = i / KA, a = i - px * KA;
+            st.dreg[e] = d[(size_t)(tile * TW + (px < TW ? px : TW - 1)) * K + (a < K ? a : K - 1)];
+        }
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int row = b0 + i * RPI + lrow;
+                st.blk[i] = *reinterpret_cast<const u32x4*>(g + (size_t)(row < B ? row : B - 1) * P + tile * TW + lcol);
+            }
+        }
+    };
+    auto write_d = [&](bf16_t* dst, const Stage& st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) {
+            const int i = tid + e * NT;
+            const int px = i / KA, a = i - px * KA;
+            if (px < TW) DImg<float>::put(dst, a * GD + px, DPL, st.dreg[e] * ((a < K) ? 1.0f : 0.0f));
+        }
+    };
+    Stage sa, sb;
+    if (t0 < t1) load_stage(sa, t0);
+    if (t0 + 1 < t1) load_stage(sb, t0 + 1);
+    if (t0 < t1) write_d(sdt, sa);
+
+    auto tile_step = [&](int tile, int dbuf, Stage& cur, Stage& oth) __attribute__((always_inline)) {
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const float f4[4] = {__uint_as_float(cur.blk[i][0]), __uint_as_float(cur.blk[i][1]),
+                                     __uint_as_float(cur.blk[i][2]), __uint_as_float(cur.blk[i][3])};
+                DImg<float>::put4(simg, (b0 + i * RPI + lrow) * GI + lcol, IPL, f4);
+            }
+        }
+        if (tile + 2 < t1) load_stage(cur, tile + 2);
+        lds_barrier();                                          // D[dbuf] visible; everyone is done reading D[dbuf^1]
+        if (active) {
+            const bf16_t* sdb = sdt + dbuf * DBUF;
+#pragma unroll
+            for (int g3 = 0; g3 < TW / 16; ++g3) {
+                const Frag a = DImg<float>::load8(simg + (b0 + c) * GI + 16 * g3 + 8 * h, IPL);
+#pragma unroll
+                for (int at = 0; at < AT; ++at)
+                    M::mma(accv[at], a, DImg<float>::load8(sdb + (at * 32 + c) * GD + 16 * g3 + 8 * h, DPL));
+            }
+        }
+        if (tile + 1 < t1) write_d(sdt + (dbuf ^ 1) * DBUF, oth);
+    };
+    for (int tile = t0; tile < t1; tile += 2) {
+        tile_step(tile, 0, sa, sb);
+        if (tile + 1 < t1) tile_step(tile + 1, 1, sb, sa);
+    }
+    if (active) {
+        float* dst = slab + (size_t)blockIdx.x * Bp * K;
+#pragma unroll
+        for (int at = 0; at < AT; ++at)
+            if (at * 32 + c < K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(size_t)(b0 + c_row(r, h)) * K + at * 32 + c] = accv[at][r];
+            }
+    }
+}
+
 // codes transposed + converted to the MFMA element type: vpt[a][b] = vp[b][a]  (a < KA, b < Bp)
 template <typename E>
 __global__ __launch_bounds__(256) void transpose_codes_kernel(const float* __restrict__ vp, int Bp, int Kp, int KA,
@@ -1452,6 +1553,18 @@ static int set_lds(const void* fn, size_t bytes) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return (int)e;
     }
+    return 0;
+}
+
+template <int AT, int NW>
+static int launch_grad_v_f32_nw(const float* g, const float* d, float* slab, int rows, int rows_p, int P, int K, int nt, int tpw,
+                                int nwg, hipStream_t st) {
+    constexpr int TW = 32;
+    const size_t lds = (2 * 3 * (size_t)AT * 32 * (TW + DPAD) + 3 * (size_t)NW * 32 * (TW + DPAD)) * sizeof(bf16_t);
+    int rc = set_lds((const void*)grad_v_f32_kernel<AT, NW>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((grad_v_f32_kernel<AT, NW>), dim3(nwg), dim3(NW * 64), lds, st, g, d, slab, rows, rows_p, P, K, nt, tpw);
+    ADIL_CHECK_LAUNCH();
     return 0;
 }
 
@@ -1611,6 +1724,24 @@ static int launch_grad_v(const T* g, const float* d, float* grad_vb, int B, int 
     const int nwg_fast = nfast > 0 ? (nfast + tpw_fast - 1) / tpw_fast : 0;
     const int tpw_slow = nslow > 0 ? (nslow + kNumCU - 1) / kNumCU : 1;
     const int nwg_slow = nslow > 0 ? (nslow + tpw_slow - 1) / tpw_slow : 0;
+    if constexpr (sizeof(T) == 4 && AT <= 2) {
+        if (vec && P % 32 == 0) {                                 // fp32 streams: planes split once, 512 rows per launch
+            const int nt = P / 32, tpw = (nt + kNumCU - 1) / kNumCU, nwg = (nt + tpw - 1) / tpw;
+            for (int r0 = 0; r0 < Bp; r0 += 512) {
+                const int rows_p = imin(Bp - r0, 512), rows = imin(B - r0, rows_p);
+                const float* gc = (const float*)g + (size_t)r0 * P;
+                int rc;
+                if (rows_p > 256) rc = launch_grad_v_f32_nw<AT, 16>(gc, d, slab, rows, rows_p, P, K, nt, tpw, nwg, st);
+                else if (rows_p > 128) rc = launch_grad_v_f32_nw<AT, 8>(gc, d, slab, rows, rows_p, P, K, nt, tpw, nwg, st);
+                else rc = launch_grad_v_f32_nw<AT, 4>(gc, d, slab, rows, rows_p, P, K, nt, tpw, nwg, st);
+                if (rc) return rc;
+                hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows_p * K + 63) / 64), dim3(256), 0, st, (const float*)slab,
+                                   nwg, rows_p, K, rows, K, grad_vb + (size_t)r0 * K);
+                ADIL_CHECK_LAUNCH();
+            }
+            return 0;
+        }
+    }
     const int chunk = GradVWaves<T, AT>::kMax * 32;
     for (int r0 = 0; r0 < Bp; r0 += chunk) {
         const int rows_p = imin(Bp - r0, chunk), rows = imin(B - r0, rows_p);

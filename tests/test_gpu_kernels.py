@@ -628,3 +628,19 @@ def test_grad_fused_fp32_presplit_kernel(b, k, hw):
     acc = gd.clone()
     ops().grad(g, d, vp, b, grad_d=acc, accumulate_d=True)
     close(acc, 2 * gd, 2e-6 * b ** 0.5 * 8)
+
+
+@pytest.mark.parametrize("b,k,hw", [(600, 50, 64), (512, 64, 32), (300, 33, 64), (200, 50, 32), (97, 10, 32), (5, 50, 224)])
+def test_grad_v_fp32_presplit_kernel(b, k, hw):
+    """v = z D_dagger^T / dL/dv = g D for fp32 streams (grad_v_f32_kernel: planes split once on the way to LDS, 512 rows
+    per launch): 16 / 8 / 4-wave workgroups, waves beyond the batch, a second chunk (600 rows), ragged rows and atoms —
+    against an fp64 matmul at fp32-grade tolerance, bitwise reproducible."""
+    gen = torch.Generator().manual_seed(3 * b + k + hw)
+    d = (-1 + 2 * torch.rand(3, hw, hw, k, generator=gen)).to(DEV)
+    g = torch.randn(b, 3, hw, hw, generator=gen).to(DEV)
+    p = 3 * hw * hw
+    _, gv = ops().grad(g, d, None, b, want_d=False)
+    assert gv.shape == (b, k)
+    close(gv, g.double().reshape(b, -1) @ d.double().reshape(-1, k), 3e-6 * p ** 0.5 * 4)
+    _, gv2 = ops().grad(g, d, None, b, want_d=False)
+    assert torch.equal(gv, gv2)
