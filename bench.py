@@ -313,6 +313,8 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
+    if reducer is not None:                                   # communicator set-up is not a step (matters with --warmup 0)
+        reducer.all_reduce_(torch.zeros(1, device=dev))
     for _ in range(args.warmup):
         step()
     sync()
