@@ -290,6 +290,13 @@ __device__ __forceinline__ void store_px4(T* rowp, int px, int P, const float (&
 // B.  Compared with 64-bit flat addresses this frees the ~2 VGPRs per outstanding access that the 16 loads + 16
 // stores of a block cost, and rows >= B need no branch: out-of-range loads return 0, out-of-range stores are dropped.
 typedef __amdgpu_buffer_rsrc_t buf_rsrc;
+// cache policy of the streaming buffer accesses (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1); tools/exp_cache_policy.sh
+#ifndef ADIL_AUX_LD
+#define ADIL_AUX_LD 0
+#endif
+#ifndef ADIL_AUX_ST
+#define ADIL_AUX_ST 0
+#endif
 __device__ __forceinline__ buf_rsrc block_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
@@ -297,7 +304,7 @@ template <typename T> struct BufPx;
 template <> struct BufPx<float> {
     typedef u32x4 Raw;
     static __device__ __forceinline__ Raw load(buf_rsrc r, int voff, int soff) {
-        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, ADIL_AUX_LD);
     }
     static __device__ __forceinline__ void unpack(const Raw& t, float (&o)[4]) {
 #pragma unroll
@@ -311,7 +318,7 @@ template <> struct BufPx<float> {
         Raw t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) t[i] = __float_as_uint(o[i]);
-        __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, ADIL_AUX_ST);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_nop 1");
         __builtin_amdgcn_sched_barrier(0);
@@ -320,7 +327,7 @@ template <> struct BufPx<float> {
 template <> struct BufPx<bf16_t> {
     typedef u32x2 Raw;
     static __device__ __forceinline__ Raw load(buf_rsrc r, int voff, int soff) {
-        return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, ADIL_AUX_LD);
     }
     static __device__ __forceinline__ void unpack(const Raw& t, float (&o)[4]) {
         o[0] = __uint_as_float(t[0] << 16); o[1] = __uint_as_float(t[0] & 0xffff0000u);
@@ -330,7 +337,7 @@ template <> struct BufPx<bf16_t> {
         Raw t;
         t[0] = pack2_bf16(o[0], o[1]);
         t[1] = pack2_bf16(o[2], o[3]);
-        __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, ADIL_AUX_ST);
     }
 };
 

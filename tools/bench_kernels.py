@@ -57,4 +57,7 @@ def iteration():
 t = timeit(iteration, n=10)
 alg = 9 * B * P * 4 + 4 * P * K * 4
 print(f"DDrague iteration (fp32, dictionary path) {t*1e3:9.1f} us  {alg/t/1e6:8.1f} GB/s algorithmic ({alg/1e9:.2f} GB)")
+gvp = ops.pack_codes(torch.randn(B, K, generator=g0).to(dev) * 0.01, None, B)
+t = timeit(lambda: ops.zstep_(z, mz, sz, dpt, gvp, B, hz, -8 / 255, 8 / 255), n=10)
+print(f"z-step (fp32) {t*1e3:9.1f} us  {(6 * B * P * 4 + P * K * 4)/t/1e6:8.1f} GB/s algorithmic")
 t = timeit(lambda: engine.PseudoInverse(d), n=5); print(f"Gram + inverse + D_dagger (once per attack call) {t*1e3:9.1f} us")
