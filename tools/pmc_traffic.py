@@ -19,21 +19,25 @@ from collections import defaultdict
 def per_kernel(dirname, counter):
     path = sorted(glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True))[0]
     acc = defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
-            continue
-        a = acc[r["Kernel_Name"]]
+    prev = ""
+    for r in sorted((r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter), key=lambda r: int(r["Dispatch_Id"])):
+        name = r["Kernel_Name"]
+        if "grad_v_reduce_kernel" in name:        # one reduce kernel serves every producer: keep them apart by the launch before
+            name = "grad_v_reduce_kernel after " + prev
+        else:
+            prev = name
+        a = acc[name]
         a[0] += float(r["Counter_Value"]); a[1] += 1
     return {k: v[0] / v[1] for k, v in acc.items()}, path
 
 
 def short(name):
-    m = re.search(r"(synth_mfma_kernel|grad_fused_mfma_kernel|grad_d_mfma_kernel|grad_v_mfma_kernel|grad_v_reduce_kernel|adamw_clamp_kernel|"
+    if name.startswith("grad_v_reduce_kernel after "):
+        return "grad_v_reduce after " + (short(name[len("grad_v_reduce_kernel after "):]) or "?")
+    m = re.search(r"(synth_mfma_kernel|grad_fused_mfma_kernel|grad_fused_f32_kernel|grad_v_f32_kernel|grad_d_mfma_kernel|grad_v_mfma_kernel|grad_v_reduce_kernel|adamw_clamp_kernel|"
                   r"adamw_l1ball_kernel|pack_codes_kernel|transpose_codes_kernel|zstep_mfma_kernel|gather_images_kernel)<([^>]*)", name)
     if m:
         return f"{m.group(1)}<{m.group(2).split('>')[0]}>"
-    if "grad_v_reduce_kernel" in name:
-        return "grad_v_reduce_kernel"
     if "direct_copy_kernel" in name or "copy" in name.lower():
         return "torch_copy"
     return None
@@ -54,11 +58,11 @@ def main():
     # the learning step's grad launch group = fused kernel + slab reduce + code transpose (the split grad_d / grad_v
     # kernels serve the single-output calls and are listed separately)
     groups = {"synth": [k for k in rows if k.startswith("synth_mfma")],
-              "grad": [k for k in rows if k.startswith(("grad_fused_mfma", "grad_v_reduce", "transpose_codes"))],
+              "grad": [k for k in rows if k.startswith(("grad_fused_mfma", "grad_v_reduce after grad_fused_mfma", "transpose_codes"))],
               "adamw_clamp_": [k for k in rows if k.startswith("adamw_clamp")],
               "adamw_l1ball_": [k for k in rows if k.startswith("adamw_l1ball")],
               "zstep_": [k for k in rows if k.startswith("zstep_mfma")],
-              "grad[z D_dagger^T]": [k for k in rows if k.startswith("grad_v_mfma_kernel<float")],
+              "grad[z D_dagger^T]": [k for k in rows if k.startswith(("grad_v_mfma_kernel<float", "grad_v_f32_kernel", "grad_v_reduce after grad_v_f32"))],
               "pack_codes": [k for k in rows if k.startswith("pack_codes")]}
     result = {"_source": {"fetch": fp, "write": wp, "correction": "hbm = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950)"},
               "_kernels": rows}
