@@ -114,6 +114,8 @@ class ADIL(Attack):
                 raise ValueError(f"unknown method {method!r} (expected 'gd' or 'alter')")
 
     # ------------------------------------------------------------------ helpers
+    _MAX_SOLVERS = 4          # graphed DDrague solvers kept per batch shape (e.g. the full batch + a ragged last one)
+
     def f_loss(self, outputs, labels):
         """CW-style margin (adil.py:103-112); `self._targeted` (always False) selects the branch, as upstream."""
         return engine.margin_loss(outputs, labels, self.kappa, self._targeted)
@@ -356,12 +358,15 @@ class ADIL(Attack):
             return engine.solve_ddrague(self.model, images, d, self.eps, self.steps_inference, self.loss,
                                         self.targeted, self.kappa, pinv=self._pinv)
         key = (tuple(images.shape), images.dtype)
-        solver = self._solvers.get(key)
+        solver = self._solvers.pop(key, None)
         if solver is None:
-            solver = self._solvers[key] = engine.DDragueSolver(self.model, images, d, self.eps, self.loss, self.targeted,
-                                                               self.kappa, pinv=self._pinv)
+            while len(self._solvers) >= self._MAX_SOLVERS:        # a solver holds z, m, s and its graph: keep a few shapes
+                self._solvers.pop(next(iter(self._solvers)))      # (oldest first; dicts keep insertion order)
+            solver = engine.DDragueSolver(self.model, images, d, self.eps, self.loss, self.targeted, self.kappa,
+                                          pinv=self._pinv)
         else:
             solver.reset(images)
+        self._solvers[key] = solver                                # most recently used last
         return solver.run(self.steps_inference, use_graph=True).result()[0]
 
     def forward_supervised_AdamW(self, images, labels, d, model='train'):

@@ -571,6 +571,12 @@ def test_graphed_ddrague_is_bit_identical(tmp_path):
     for x in batches:
         assert torch.equal(a(x, lab), b(x, lab))
     assert len(b._solvers) == 1 and next(iter(b._solvers.values()))._graph is not None
+    # the cache is bounded (a solver holds z, m, s and a graph): other batch sizes evict the least recently used shape
+    for n in (1, 2, 3, 4, 2):
+        x = batches[0][:n]
+        assert torch.equal(a(x, lab[:n]), b(x, lab[:n]))
+    assert len(b._solvers) == ADIL._MAX_SOLVERS and (5, 3, 32, 32) not in [k[0] for k in b._solvers]
+    assert list(b._solvers)[-1][0] == (2, 3, 32, 32)
     # convergence inside a replayed group: a zero dictionary direction makes every z-step a no-op from the start
     flat = make_tinynet(6).to(DEV)
     for p in flat.parameters():
