@@ -62,6 +62,9 @@ class ADIL(Attack):
       stream_dtype   torch.float32 (default) or torch.bfloat16 for the image-shaped streams x+Dv and dLoss/dx
       dict_dir       folder of the dictionary file (default 'trained_dicts')
       shuffle_seed   seed of the per-epoch global batches of the data-parallel learner (identical on every rank)
+      cache_labels   learners: compute the clean pseudo-label of an image once (first epoch) instead of in every epoch
+                     (engine.LabelCache; saves one of the two classifier forwards per step; default False = the
+                     reference's op sequence)
       use_graph      replay the learning step (engine.DictionaryLearner.step_graphed) and the DDrague inference iterations
                      (engine.DDragueSolver.run, three per launch) as hipGraph launches: for launch-bound uses — small
                      batches, the one-image attack of main.py; default: $ADIL_GRAPH == "1"
@@ -73,7 +76,7 @@ class ADIL(Attack):
                  data_train=None, data_val=None, trials=10, attack='supervised', model_name=None, step_size=0.01,
                  is_distributed=False, steps_in=None, loss='ce', method='gd', warm_start=False, kappa=50,
                  steps_inference=30, alpha=None, init_d=None, init_v=None, epoch_batches=None, val_batches=None,
-                 stream_dtype=None, dict_dir='trained_dicts', shuffle_seed=0, use_graph=None):
+                 stream_dtype=None, dict_dir='trained_dicts', shuffle_seed=0, use_graph=None, cache_labels=False):
         super().__init__("ADIL", model.eval())
         self.norm = norm.lower()
         self.eps = eps
@@ -96,6 +99,7 @@ class ADIL(Attack):
         self._epoch_batches, self._val_batches = epoch_batches, val_batches
         self._shuffle_seed = int(shuffle_seed)
         self._use_graph = (os.environ.get("ADIL_GRAPH") == "1") if use_graph is None else bool(use_graph)
+        self._cache_labels = bool(cache_labels)
         self._pinv = None
         self._solvers = {}
         self._dict_mtime = None
@@ -156,6 +160,14 @@ class ADIL(Attack):
             return [[int(i) for i in idx] for idx in explicit[epoch]]
         return shuffled_batches(n, batch_size)
 
+    def _labelled_batches(self, train, order):
+        """(index, x, labels) per batch; labels is None (the learner recomputes them, adil.py:172) unless cache_labels."""
+        order = [list(idx) for idx in order]
+        if self._cache_labels and getattr(train, "_label_cache", None) is None:
+            train._label_cache = engine.LabelCache(len(train), self.device)
+        for rows, (index, x) in zip(order, train.batches(order)):
+            yield index, x, (train._label_cache.get(self.model, x, index, rows) if self._cache_labels and len(rows) else None)
+
     def _validate(self, val, epoch, d, batch_size):
         """Per-epoch validation through forward_supervised_AdamW in 'train' mode (adil.py:199-205).
         `val` is a ResidentImages (or None)."""
@@ -192,8 +204,11 @@ class ADIL(Attack):
         for iteration in range(int(self.steps)):
             loss_full = torch.zeros((), dtype=torch.float32, device=self.device)
             fooled = torch.zeros((), dtype=torch.int64, device=self.device)
-            for index, x in train.batches(self._epoch_order(n_img, batch_size, self._epoch_batches, iteration)):
-                ls, fl = (learner.step_graphed if self._use_graph else learner.step)(self.model, x, index)   # adil.py:168-191
+            for index, x, lab in self._labelled_batches(train, self._epoch_order(n_img, batch_size, self._epoch_batches, iteration)):
+                if self._use_graph and lab is None:
+                    ls, fl = learner.step_graphed(self.model, x, index)
+                else:
+                    ls, fl = learner.step(self.model, x, index, lab)                       # adil.py:168-191
                 loss_full += ls
                 fooled += fl
             loss_all.append(loss_full.item() / n_img)                                      # adil.py:194
@@ -224,14 +239,14 @@ class ADIL(Attack):
         epoch = 0
         for iteration in range(int(self.steps // self.steps_inner)):
             for _ in range(self.steps_inner):                                              # V-steps, adil.py:265-289
-                for index, x in train.batches(self._epoch_order(n_img, batch_size, self._epoch_batches, epoch)):
-                    learner.step_codes(self.model, x, index)
+                for index, x, lab in self._labelled_batches(train, self._epoch_order(n_img, batch_size, self._epoch_batches, epoch)):
+                    learner.step_codes(self.model, x, index, lab)
                 epoch += 1
             for _ in range(self.steps_inner):                                              # D-steps, adil.py:292-314
                 fooled = torch.zeros((), dtype=torch.int64, device=self.device)
                 ls = None
-                for index, x in train.batches(self._epoch_order(n_img, batch_size, self._epoch_batches, epoch)):
-                    ls, fl = learner.step_dictionary(self.model, x, index)
+                for index, x, lab in self._labelled_batches(train, self._epoch_order(n_img, batch_size, self._epoch_batches, epoch)):
+                    ls, fl = learner.step_dictionary(self.model, x, index, lab)
                     fooled += fl
                 epoch += 1
             loss_all.append(ls.item() / n_img)               # last batch only — reference quirk Q11 (adil.py:313-317)
@@ -283,8 +298,8 @@ class ADIL(Attack):
             else:
                 order = global_epoch_batches(n_img, batch_size, world, self._shuffle_seed, iteration)
             local = [[i - lo for i in owned_rows(gb, lo, hi)] for gb in order]
-            for index, x in train.batches(local):
-                ls, fl = learner.step(self.model, x, index)
+            for index, x, lab in self._labelled_batches(train, local):
+                ls, fl = learner.step(self.model, x, index, lab)
                 loss_full += ls
                 fooled += fl
             tot_loss, tot_fooled = reducer.sum_scalars(loss_full, fooled)         # adil.py:418-419

@@ -67,6 +67,33 @@ def _flat_images(x: Tensor) -> Tensor:
     return x.contiguous()
 
 
+class LabelCache:
+    """Clean pseudo-labels per image of a resident dataset, computed on the first visit and reused afterwards.
+
+    The learners of the reference recompute `model(x).argmax` for the same clean images in every epoch (adil.py:172,
+    268, 295).  The classifier is frozen and in eval mode, so the label is a constant of the image: after the first
+    epoch the second forward of every step is pure recomputation (a third of the step's classifier time).  Opt-in
+    (`ADIL(cache_labels=True)`), because the reference's value comes from whatever batch the image is in that epoch and a
+    library may round the logits of an image differently in a different batch — a near-tie could flip; the default keeps
+    the reference's op sequence.  Which rows are known is tracked on the host (the batch order is host data), so a lookup
+    costs no synchronisation."""
+
+    def __init__(self, n: int, device):
+        self.labels = torch.full((n,), -1, dtype=torch.int64, device=device)
+        self._known = [False] * n
+
+    def get(self, model, x: Tensor, index: Tensor, rows) -> Tensor:
+        """Labels of the batch `x` = resident rows `rows` (host ints; `index` is the same on the device)."""
+        rows = [int(r) for r in rows]
+        if all(self._known[r] for r in rows):
+            return self.labels[index]
+        lab = predict(model, x)
+        self.labels[index] = lab
+        for r in rows:
+            self._known[r] = True
+        return lab
+
+
 # --------------------------------------------------------------------------- #
 class DictionaryLearner:
     """State + fused update of the learnable pair (D, V) of Attack_dict_model (adil.py:16-35).

@@ -604,3 +604,39 @@ def test_main_cli_one_image_attack(graph, tmp_path, monkeypatch):
     test_main_cli_one_image_attack.seen[graph] = out
     if len(test_main_cli_one_image_attack.seen) == 2:
         assert test_main_cli_one_image_attack.seen[0] == test_main_cli_one_image_attack.seen[1]
+
+
+@pytest.mark.parametrize("method", ["gd", "alter"])
+def test_cached_pseudo_labels_match_the_golden_runs(method, tmp_path):
+    """ADIL(cache_labels=True): the clean pseudo-label of an image is computed on its first visit and reused in later
+    epochs (engine.LabelCache) instead of one extra classifier forward per step.  Same golden trajectories as the
+    recomputing learners (G7 logits / G8: D, V, fooling rates exact), and the classifier really runs fewer forwards."""
+    from attacks import ADIL
+    z = load_golden("g7_learn_a" if method == "gd" else "g8_learn_b")
+    net = net_on_gpu(z)
+    calls = {"n": 0}
+    hook = net.register_forward_hook(lambda *a: calls.__setitem__("n", calls["n"] + 1))
+    tag = "logits_" if method == "gd" else ""
+    common = dict(eps=float(z[f"{tag}eps"]), steps=int(z["steps"]), norm="linf", n_atoms=int(z["k"]),
+                  batch_size=int(z["batch_size"]), data_val=None, step_size=float(z["step_size"]), loss="logits",
+                  method=method, kappa=float(z["kappa"]), init_d=t(z[f"{tag}d0"]), epoch_batches=z[f"{tag}batches"].tolist(),
+                  dict_dir=str(tmp_path))
+    if method == "gd":
+        common.update(init_v=t(z["logits_v0raw"]))
+    else:
+        common.update(init_v=torch.zeros(z["v0"].shape), steps_in=int(z["steps_in"]))
+    runs = {}
+    for cached in (False, True):
+        calls["n"] = 0
+        atk = ADIL(net, data_train=IndexedTensorDataset(t(z["images"])), model_name=f"lc{method}{int(cached)}",
+                   cache_labels=cached, **common)
+        runs[cached] = (torch.load(atk.model_file, map_location="cpu"), calls["n"])
+    hook.remove()
+    (d0, v0, l0, f0, _), n0 = runs[False]
+    (d1, v1, l1, f1, _), n1 = runs[True]
+    assert torch.equal(d0, d1) and torch.equal(v0, v1) and l0 == l1 and f0 == f1
+    close(d1, z[f"{tag}d"], TOL_D, "D"); close(v1, z[f"{tag}v"], TOL_V, "V")
+    assert list(f1) == list(z[f"{tag}fooling_rate_all"])
+    steps_total = sum(len(e) for e in common["epoch_batches"][:len(l0) * (1 if method == "gd" else 2 * common.get("steps_in", 1))])
+    first_epoch = len(common["epoch_batches"][0])
+    assert n0 == 2 * steps_total and n1 == steps_total + first_epoch, (n0, n1, steps_total, first_epoch)
