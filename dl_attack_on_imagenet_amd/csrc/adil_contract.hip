@@ -1067,12 +1067,14 @@ template <> struct ColFrag<float> {
     }
 };
 
-template <typename T, int AT, int NW, int RB, bool FAST, bool ACC>
+template <typename T, int AT, int NW, int RB, bool FAST, bool ACC, bool WV = true>
 __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __restrict__ g, const float* __restrict__ d,
                                                                   const typename Mma<T>::Elem* __restrict__ vpt,
                                                                   int vstride, float* __restrict__ grad_d,
                                                                   float* __restrict__ slab, int B, int Bp, int P, int K,
                                                                   int tile_begin, int tile_end, int tiles_per_wg) {
+    // WV = false: the grad_d half alone (no D tile, no grad_v accumulators, no slab) — the LDS-staged grad_d kernel of
+    // K > 64, where the direct-load kernel is left with 128-byte row pieces (finding 17) and the fused kernel with 256 rows.
     // NW waves, each owning RB consecutive 32-row batch blocks (RB = 2 keeps the 512-row workgroup at 8 waves, i.e.
     // a 256-register budget per wave: with 16 waves the 128-register cap spills, and a scratch reload behind the
     // prefetched loads drains vmcnt and serialises the stream).
@@ -1095,20 +1097,22 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
     constexpr int GD = GV_TW + DPAD, DPL = KA * GD, DBUF = DImg<T>::PLANES * DPL;   // D tile: planes of [KA][GD] bf16
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sdt = reinterpret_cast<bf16_t*>(smem_raw);           // [2][PLANES][KA][GD]
-    E* simg = reinterpret_cast<E*>(sdt + 2 * DBUF);              // [NBLK][32][GS]  the g block of this tile
+    E* simg = reinterpret_cast<E*>(sdt + (WV ? 2 * DBUF : 0));   // [NBLK][32][GS]  the g block of this tile
     float* red = reinterpret_cast<float*>(simg + NBLK * 32 * GS);   // [NW][16][64]  grad_d row-split partials
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int t0 = tile_begin + blockIdx.x * tiles_per_wg;
     const int t1 = min(tile_end, t0 + tiles_per_wg);
     const int ti = w % NTILE, ks = w / NTILE, tp = ti & 1, ta = ti >> 1;
 
-    f32x16 accv[RB][AT];
+    f32x16 accv[WV ? RB : 1][WV ? AT : 1];
+    if constexpr (WV) {
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int at = 0; at < AT; ++at)
+            for (int at = 0; at < AT; ++at)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) accv[rb][at][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) accv[rb][at][r] = 0.0f;
+    }
     const int lrow = lane / LPR, lcol = (lane - lrow * LPR) * EPL;
 
     // tile-invariant B fragments of grad_d: codes (transposed, converted) of this wave's row split
@@ -1128,11 +1132,11 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
     float dreg[DPT];
     u32x4 blk[RB][NLD];
     if (t0 < t1) {
-        gv_load_d<T, AT, NW, FAST>(d, t0, P, K, tid, dreg);
+        if constexpr (WV) gv_load_d<T, AT, NW, FAST>(d, t0, P, K, tid, dreg);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
             if ((w * RB + rb) * 32 < Bp) gv_load_g<T, FAST>(g, t0, (w * RB + rb) * 32, B, P, lrow, lcol, blk[rb]);
-        gv_write_d<T, AT, NW, FAST>(sdt, t0, P, K, tid, dreg);
+        if constexpr (WV) gv_write_d<T, AT, NW, FAST>(sdt, t0, P, K, tid, dreg);
     }
     for (int tile = t0; tile < t1; ++tile) {
         const int buf = (tile - t0) & 1;
@@ -1160,13 +1164,13 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
             }
         }
         if (more) {                                               // next tile's loads fly under this tile's MFMAs
-            gv_load_d<T, AT, NW, FAST>(d, tile + 1, P, K, tid, dreg);
+            if constexpr (WV) gv_load_d<T, AT, NW, FAST>(d, tile + 1, P, K, tid, dreg);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
                 if ((w * RB + rb) * 32 < Bp) gv_load_g<T, FAST>(g, tile + 1, (w * RB + rb) * 32, B, P, lrow, lcol, blk[rb]);
         }
         lds_barrier();                                          // all images + D[buf] visible
-        {                                                         // ---- grad_v: rows of this wave, all 64 pixels
+        if constexpr (WV) {                                       // ---- grad_v: rows of this wave, all 64 pixels
             const bf16_t* sdb = sdt + buf * DBUF;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -1235,8 +1239,11 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
             }
         }
         if (KS == 1) lds_barrier();                             // image reads done before the next tile overwrites
-        if (more) gv_write_d<T, AT, NW, FAST>(sdt + (buf ^ 1) * DBUF, tile + 1, P, K, tid, dreg);
+        if constexpr (WV) {
+            if (more) gv_write_d<T, AT, NW, FAST>(sdt + (buf ^ 1) * DBUF, tile + 1, P, K, tid, dreg);
+        }
     }
+    if constexpr (WV) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int b0 = (w * RB + rb) * 32;
@@ -1249,6 +1256,7 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
                     for (int r = 0; r < 16; ++r) dst[(size_t)(b0 + c_row(r, h)) * K + at * 32 + c] = accv[rb][at][r];
                 }
         }
+    }
     }
 }
 
@@ -1879,6 +1887,61 @@ static int launch_grad_fused(const T* g, const float* d, const float* vp, float*
     return 0;
 }
 
+// ---- grad_d alone through LDS (K > 64, bf16 streams): the grad_d half of the fused kernel, 512 rows per launch -------- //
+template <typename T, int AT, int NW, int RB, bool FAST>
+static int launch_grad_d_lds_nw(const T* g, const typename Mma<T>::Elem* vpt, int vstride, float* grad_d, int rows, int rows_p,
+                                int P, int K, int acc_d, int tile_begin, int tile_end, int nwg, int tpw, hipStream_t st) {
+    using E = typename Mma<T>::Elem;
+    if (nwg <= 0) return 0;
+    const size_t lds = (size_t)NW * RB * 32 * (GV_TW + Mma<T>::PAD) * sizeof(E) + (size_t)NW * 16 * 64 * sizeof(float);
+    if (acc_d) {
+        int rc = set_lds((const void*)grad_fused_mfma_kernel<T, AT, NW, RB, FAST, true, false>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((grad_fused_mfma_kernel<T, AT, NW, RB, FAST, true, false>), dim3(nwg), dim3(NW * 64), lds, st, g,
+                           (const float*)nullptr, vpt, vstride, grad_d, (float*)nullptr, rows, rows_p, P, K, tile_begin, tile_end, tpw);
+    } else {
+        int rc = set_lds((const void*)grad_fused_mfma_kernel<T, AT, NW, RB, FAST, false, false>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((grad_fused_mfma_kernel<T, AT, NW, RB, FAST, false, false>), dim3(nwg), dim3(NW * 64), lds, st, g,
+                           (const float*)nullptr, vpt, vstride, grad_d, (float*)nullptr, rows, rows_p, P, K, tile_begin, tile_end, tpw);
+    }
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T, int AT>
+static int launch_grad_d_lds(const T* g, const float* vp, float* grad_d, int B, int P, int K, int accumulate_d, void* ws,
+                             hipStream_t st) {
+    using E = typename Mma<T>::Elem;
+    constexpr int KA = AT * 32;
+    const int Kp = round_up(K, 16), Bp = round_up(B, 32);
+    E* vpt = reinterpret_cast<E*>(ws);
+    hipLaunchKernelGGL((transpose_codes_kernel<E>), dim3((KA * Bp + 255) / 256), dim3(256), 0, st, vp, Bp, Kp, KA, vpt);
+    ADIL_CHECK_LAUNCH();
+    const int ntiles = (P + GV_TW - 1) / GV_TW;
+    const bool vec = (P % 8 == 0) && ((uintptr_t)g % 16 == 0);
+    const int nfast = vec ? P / GV_TW : 0, nslow = ntiles - nfast;
+    const int tpw_fast = nfast > 0 ? (nfast + kNumCU - 1) / kNumCU : 1, nwg_fast = nfast > 0 ? (nfast + tpw_fast - 1) / tpw_fast : 0;
+    const int tpw_slow = nslow > 0 ? (nslow + kNumCU - 1) / kNumCU : 1, nwg_slow = nslow > 0 ? (nslow + tpw_slow - 1) / tpw_slow : 0;
+    for (int r0 = 0; r0 < Bp; r0 += 512) {
+        const int rows_p = imin(Bp - r0, 512), rows = imin(B - r0, rows_p);
+        const T* gc = g + (size_t)r0 * P;
+        const int acc_d = accumulate_d || (r0 > 0);
+        int rc;
+        if (rows_p > 256) {
+            rc = launch_grad_d_lds_nw<T, AT, 8, 2, true>(gc, vpt + r0, Bp, grad_d, rows, rows_p, P, K, acc_d, 0, nfast, nwg_fast, tpw_fast, st);
+            if (rc) return rc;
+            rc = launch_grad_d_lds_nw<T, AT, 8, 2, false>(gc, vpt + r0, Bp, grad_d, rows, rows_p, P, K, acc_d, nfast, ntiles, nwg_slow, tpw_slow, st);
+        } else {
+            rc = launch_grad_d_lds_nw<T, AT, 8, 1, true>(gc, vpt + r0, Bp, grad_d, rows, rows_p, P, K, acc_d, 0, nfast, nwg_fast, tpw_fast, st);
+            if (rc) return rc;
+            rc = launch_grad_d_lds_nw<T, AT, 8, 1, false>(gc, vpt + r0, Bp, grad_d, rows, rows_p, P, K, acc_d, nfast, ntiles, nwg_slow, tpw_slow, st);
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 template <typename T, int PXT, int AT>
 static int launch_grad_cfg(const T* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P,
                            int K, int accumulate_d, void* ws, hipStream_t st) {
@@ -1891,13 +1954,21 @@ static int launch_grad_cfg(const T* g, const float* d, const float* vp, float* g
         // ACC variant: old tile values requested before the next tile's loads so that waiting for them does not drain the
         // prefetch).  Measured, fused chunks vs the two single-output kernels: bf16 1024 rows K=50 (2 chunks) 128 vs 198 us;
         // fp32 512 rows K=50 (2 chunks) 233 vs 242 us; bf16 2048 rows K=50 (4 chunks) 248 vs 360 us; bf16 1024 rows K=100
-        // (4 chunks) 291.5 vs 291.3 us; 768 rows K=100 (3 chunks) 214 vs 234 us.
+        // (4 chunks) 291.5 vs 291.3 us; 768 rows K=100 (3 chunks) 214 vs 234 us — with the direct-load grad_d kernel.  With
+        // grad_d through LDS (launch_grad_d_lds) the two single-output kernels win for K > 64 from the second chunk on:
+        // 512 rows 102 vs 135 us, 768 rows 194 vs 214, 1024 rows 253 vs 292.
         constexpr int kRows = FusedCfg<T, AT>::kMaxRows;
-        const bool fused = Bp <= 4 * kRows;
+        // K > 64: a fused launch holds 256 rows only (its grad_v accumulators), so beyond one chunk the two single-output
+        // kernels win once grad_d goes through LDS in 512-row launches (launch_grad_d_lds)
+        const bool fused = (AT == 4 && sizeof(T) == 2) ? Bp <= kRows : Bp <= 4 * kRows;
         if (grad_d != nullptr && grad_vb != nullptr && fused)
             return launch_grad_fused<T, AT>(g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, slab, st);
     }
-    if (grad_d != nullptr) rc = launch_grad_d<T, PXT, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, st);
+    if constexpr (AT == 4 && sizeof(T) == 2) {
+        if (grad_d != nullptr) rc = launch_grad_d_lds<T, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, st);
+    } else {
+        if (grad_d != nullptr) rc = launch_grad_d<T, PXT, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, st);
+    }
     if (rc) return rc;
     if (grad_vb != nullptr) rc = launch_grad_v<T, AT>(g, d, grad_vb, B, P, K, slab, st);
     return rc;

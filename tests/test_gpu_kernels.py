@@ -644,3 +644,34 @@ def test_grad_v_fp32_presplit_kernel(b, k, hw):
     close(gv, g.double().reshape(b, -1) @ d.double().reshape(-1, k), 3e-6 * p ** 0.5 * 4)
     _, gv2 = ops().grad(g, d, None, b, want_d=False)
     assert torch.equal(gv, gv2)
+
+
+@pytest.mark.parametrize("b,k,c,h,w", [(512, 100, 3, 32, 32), (300, 65, 3, 16, 24), (700, 128, 3, 16, 16), (1024, 100, 3, 16, 16),
+                                       (257, 100, 3, 9, 7), (200, 100, 3, 16, 16)])
+def test_grad_bf16_many_atoms(b, k, c, h, w):
+    """K > 64 on bf16 streams: up to 256 rows one fused launch; beyond that grad_d through LDS in 512-row launches (the
+    grad_d half of the fused kernel; the second chunk accumulates) + the grad_v kernel.  Ragged rows / pixels / atoms,
+    grad_d alone, accumulation into an existing grad_d, against fp64 matmuls on the bf16-rounded operands, reproducible."""
+    gen = torch.Generator().manual_seed(b + k + h)
+    d = (-1 + 2 * torch.rand(c, h, w, k, generator=gen)).to(DEV)
+    v = (torch.randn(b, k, generator=gen) * 0.02).to(DEV)
+    g = torch.randn(b, c, h, w, generator=gen).to(DEV).bfloat16()
+    p = c * h * w
+    vp = ops().pack_codes(v, None, b)
+    gd, gvb = ops().grad(g, d, vp, b)
+    g2 = g.double().reshape(b, p)
+    rd = g2.t() @ v.bfloat16().double()
+    rv = g2 @ d.bfloat16().double().reshape(p, k)
+    close(gd.reshape(p, k), rd, 1e-5 * b ** 0.5 * 4)
+    close(gvb, rv, 1e-5 * p ** 0.5 * 4)
+    gd_only, none = ops().grad(g, d, vp, b, want_v=False)
+    assert none is None
+    close(gd_only.reshape(p, k), rd, 1e-5 * b ** 0.5 * 4)
+    gd2, gvb2 = ops().grad(g, d, vp, b)
+    assert torch.equal(gd, gd2) and torch.equal(gvb, gvb2)
+    acc = gd.clone()
+    ops().grad(g, d, vp, b, grad_d=acc, accumulate_d=True)
+    close(acc, 2 * gd, 1e-5 * b ** 0.5 * 8)
+    acc = gd_only.clone()
+    ops().grad(g, d, vp, b, want_v=False, grad_d=acc, accumulate_d=True)
+    close(acc, 2 * gd_only, 1e-5 * b ** 0.5 * 8)
