@@ -466,10 +466,11 @@ __device__ __forceinline__ void synth_store_buf(const f32x16 (&acc)[4], buf_rsrc
 }
 
 // Aligned-interior sweep (FAST tiles): buffer addressing (see BufPx) and the code fragments of the first
-// SYNTH_HOIST k-groups loaded up front, BEFORE the 16 x loads, so that per batch block a wave pays one L2 round trip
+// HOIST k-groups loaded up front, BEFORE the 16 x loads, so that per batch block a wave pays one L2 round trip
 // for its codes (hidden under the HBM latency of x) instead of one per k-group in the MFMA loop.
-#define SYNTH_HOIST 4
-template <typename T, typename O, bool XACC>
+// HOIST = 4 covers K <= 64; K > 64 runs the HOIST = 8 instantiation (all k-groups up front; costs ~45 registers, i.e. one
+// resident workgroup per CU less, which the K <= 64 stream cannot afford)
+template <typename T, typename O, bool XACC, int HOIST>
 __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const float* __restrict__ vp,
                                                 T* __restrict__ out, const typename DImg<O>::Elem* sd, int B, int P,
                                                 int Kp, int Ks, int p0, float delta_clamp, int pixel_clamp, int w, int c,
@@ -493,9 +494,9 @@ __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const f
             for (int reg = 0; reg < 16; ++reg) xr[reg] = BP::load(rx, voff, (int)((unsigned)c_row(reg, 0) * rowb));
         }
         const float* arow = vp + (size_t)(b0 + c) * Kp + 8 * h;
-        float4 araw[SYNTH_HOIST][2];
+        float4 araw[HOIST][2];
 #pragma unroll
-        for (int g = 0; g < SYNTH_HOIST; ++g) {
+        for (int g = 0; g < HOIST; ++g) {
             const float* ap = arow + 16 * (g < NG ? g : NG - 1);
             araw[g][0] = *reinterpret_cast<const float4*>(ap);
             araw[g][1] = *reinterpret_cast<const float4*>(ap + 4);
@@ -504,9 +505,9 @@ __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const f
         // (and their conversion) into the `g < NG` blocks next to their MFMAs: one exposed L2 round trip per k-group.
         // The opaque uses below pin them here (the x loads were issued first, so nothing waits longer than it must).
         __builtin_amdgcn_sched_barrier(0);
-        Frag a[SYNTH_HOIST];
+        Frag a[HOIST];
 #pragma unroll
-        for (int g = 0; g < SYNTH_HOIST; ++g) {
+        for (int g = 0; g < HOIST; ++g) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 asm volatile("" : "+v"(araw[g][u].x), "+v"(araw[g][u].y), "+v"(araw[g][u].z), "+v"(araw[g][u].w));
@@ -527,13 +528,13 @@ __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const f
             for (int t = 0; t < 4; ++t) acc[t][reg] = M::SCALED ? xv[t] * (sc.v * sc.d) : xv[t];
         }
 #pragma unroll
-        for (int g = 0; g < SYNTH_HOIST; ++g) {
+        for (int g = 0; g < HOIST; ++g) {
             if (g < NG) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) M::mma(acc[t], a[g], DImg<O>::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h, plane));
             }
         }
-        for (int g = SYNTH_HOIST; g < NG; ++g) {                                         // K > 64
+        for (int g = HOIST; g < NG; ++g) {                                         // K > 64
             const Frag ag = frag_from_f32x8<O>(arow + 16 * g, sc.v);
 #pragma unroll
             for (int t = 0; t < 4; ++t) M::mma(acc[t], ag, DImg<O>::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h, plane));
@@ -622,7 +623,7 @@ __device__ __forceinline__ void fill_dict_slice(const float* __restrict__ d, typ
     }
 }
 
-template <typename T, typename O, bool XACC, bool FAST>
+template <typename T, typename O, bool XACC, bool FAST, int HOIST = 4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void synth_mfma_kernel(const T* __restrict__ x, const float* __restrict__ d,
                                                          const float* __restrict__ vp, T* __restrict__ out, int B,
                                                          int P, int K, int Kp, float delta_clamp, int pixel_clamp,
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
     fill_dict_slice<O, FAST>(d, sd, p0, P, K, Kp, Ks, tid, sc.d);
     __syncthreads();
     if constexpr (FAST)
-        synth_sweep_buf<T, O, XACC>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp,
+        synth_sweep_buf<T, O, XACC, HOIST>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp,
                                     __builtin_amdgcn_readfirstlane(w), c, h, sc);
     else
         synth_sweep<T, O, XACC, FAST>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp, w, c, h, sc);
@@ -1601,6 +1602,16 @@ static int launch_synth_range(const void* x, const float* d, const float* vp, vo
     if (ntiles <= 0) return 0;
     const int Kp = round_up(K, 16);
     const size_t lds = (size_t)DImg<O>::PLANES * SYNTH_TILE * (Kp + DPAD) * sizeof(typename DImg<O>::Elem);
+    if constexpr (FAST && sizeof(typename Mma<O>::Frag) <= 16) {      // (fp32 operands: 12 registers per split fragment, 8 do not fit)
+        if (Kp > 64) {                                            // all k-groups' code fragments hoisted (see synth_sweep_buf)
+            int rc = set_lds((const void*)synth_mfma_kernel<T, O, XACC, true, 8>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((synth_mfma_kernel<T, O, XACC, true, 8>), dim3(ntiles), dim3(256), lds, st, (const T*)x, d, vp,
+                               (T*)out, B, P, K, Kp, delta_clamp, pixel_clamp, tile0, sc);
+            ADIL_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     int rc = set_lds((const void*)synth_mfma_kernel<T, O, XACC, FAST>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((synth_mfma_kernel<T, O, XACC, FAST>), dim3(ntiles), dim3(256), lds, st, (const T*)x, d, vp, (T*)out,
