@@ -44,9 +44,53 @@ def attack_loss(outputs: Tensor, labels: Tensor, loss: str, coeff: float, kappa:
     raise ValueError(f"unknown loss {loss!r} (expected 'ce' or 'logits')")
 
 
+# --------------------------------------------------------------------------- #
+# the frozen classifier, called at a few batch sizes only
+# --------------------------------------------------------------------------- #
+_BATCH_BUCKET = 0
+
+
+class classifier_batch_bucket:
+    """Round the batch the frozen classifier sees up to a multiple of `multiple` (rows of zeros appended, their logits
+    and input gradients dropped), so that it runs at a handful of batch sizes instead of every size a caller produces.
+
+    Why: on this stack MIOpen goes through its find / compile step for every convolution configuration it has not
+    seen, i.e. for every NEW batch size: 0.6-1.0 s (MobileNetV2, fp32) to 2.2-3.2 s (ResNet-50, bf16) for the first
+    forward + backward at a size against 5-8 ms afterwards (tools/exp_ragged_batches.py, DESIGN finding 23) — and
+    performance.py's correctly-classified filter (performance.py:163-165) hands the attack a different number of
+    images per batch.  The attack's own arithmetic is untouched: the loss, its mean, the stop test and every ADiL
+    kernel see the real rows only; an eval-mode classifier treats the rows of a batch independently.
+    Use as a context manager (`with classifier_batch_bucket(20): ...`) or call `.set()` / `.clear()`; 0 / 1 = off."""
+
+    def __init__(self, multiple: int):
+        self.multiple, self._prev = int(multiple), 0
+
+    def set(self):
+        global _BATCH_BUCKET
+        self._prev, _BATCH_BUCKET = _BATCH_BUCKET, self.multiple
+        return self
+
+    def clear(self):
+        global _BATCH_BUCKET
+        _BATCH_BUCKET = self._prev
+
+    __enter__ = set
+
+    def __exit__(self, *exc):
+        self.clear()
+
+
+def _padded_rows(x: Tensor) -> Tensor:
+    n = x.shape[0]
+    if _BATCH_BUCKET <= 1 or n == 0 or n % _BATCH_BUCKET == 0:
+        return x
+    pad = x.new_zeros((_BATCH_BUCKET - n % _BATCH_BUCKET,) + tuple(x.shape[1:]))
+    return torch.cat([x, pad])
+
+
 @torch.no_grad()
 def predict(model, x: Tensor) -> Tensor:
-    return model(x).argmax(dim=-1)
+    return model(_padded_rows(x))[:x.shape[0]].argmax(dim=-1)
 
 
 def input_gradient(model, xt: Tensor, labels: Tensor, loss: str, coeff: float, kappa: float,
@@ -55,7 +99,7 @@ def input_gradient(model, xt: Tensor, labels: Tensor, loss: str, coeff: float, k
     classifier's weight gradients (the reference computes and discards them, quirk Q8)."""
     xt = xt.detach().requires_grad_(True)
     with torch.enable_grad():
-        out = model(xt)
+        out = model(_padded_rows(xt))[:xt.shape[0]]
         ls = attack_loss(out, labels, loss, coeff, kappa, ce_reduction)
         (g,) = torch.autograd.grad(ls, xt)
     return out.detach(), ls.detach(), g.contiguous()

@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-from dl_attack_on_imagenet_amd import ops
+from dl_attack_on_imagenet_amd import engine, ops
 from dl_attack_on_imagenet_amd import dist as adist
 
 
@@ -28,6 +28,11 @@ def _sum_over_ranks(values, device):
     """Element-wise sum of a flat list of python floats over all ranks (one small all-reduce)."""
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
     return adist.all_reduce_(t).tolist()
+
+
+def _loader_batch_size(data):
+    """Batch size of a DataLoader-like object (0 = unknown: no bucketing)."""
+    return int(getattr(data, "batch_size", 0) or 0)
 
 
 def get_args(args):
@@ -80,21 +85,24 @@ def performance(attack, model, data, device=torch.device('cpu')):
     num_samples, fooling, rmse, mse = 0, 0, 0, 0
     device = attack.device
     rank, world = _rank_world()
-    for i, (x, y) in enumerate(data):
-        if i % world != rank:
-            continue
-        x, y = x.to(device=device), y.to(device=device)
-        keep = model(x).argmax(dim=-1) == y                                  # performance.py:162-164
-        x, y = x[keep].contiguous(), y[keep]
-        num_samples += torch.sum(keep)
-        adversary = attack(x, y)
-        if isinstance(adversary, tuple):                                     # unsupervised attack returns a tuple
-            adversary = adversary[0]
-        adversary = adversary.detach()
-        fooling += compute_fooling_rate(model=model.eval(), adversary=adversary, clean=x)
-        r, m = _rmse_mse(adversary, x)
-        rmse += r
-        mse += m
+    # the filter below gives every batch its own size; the classifier still only ever runs at the loader's batch size
+    # (engine.classifier_batch_bucket: a new size costs MIOpen seconds of find / compile on this stack)
+    with engine.classifier_batch_bucket(_loader_batch_size(data)):
+        for i, (x, y) in enumerate(data):
+            if i % world != rank:
+                continue
+            x, y = x.to(device=device), y.to(device=device)
+            keep = engine.predict(model, x) == y                             # performance.py:162-164
+            x, y = x[keep].contiguous(), y[keep]
+            num_samples += torch.sum(keep)
+            adversary = attack(x, y)
+            if isinstance(adversary, tuple):                                 # unsupervised attack returns a tuple
+                adversary = adversary[0]
+            adversary = adversary.detach()
+            fooling += compute_fooling_rate(model=model.eval(), adversary=adversary, clean=x)
+            r, m = _rmse_mse(adversary, x)
+            rmse += r
+            mse += m
     if world > 1:
         num_samples, fooling, rmse, mse = _sum_over_ranks([float(num_samples), fooling, rmse, mse], device)
     print(num_samples)
@@ -122,21 +130,22 @@ def get_transfer_performance_aux(attack, model_transfer, data, device=torch.devi
     num_samples = len(data.dataset)
     perf = {name: {'fooling_rate': 0., 'rmse': 0., 'mse': 0.} for name in model_transfer.keys()}
     rank, world = _rank_world()
-    for i, (x, y) in enumerate(data):
-        if i % world != rank:
-            continue
-        x, y = x.to(device=device), y.to(device=device)
-        adversary = attack(x, y)
-        if isinstance(adversary, tuple):
-            adversary = adversary[0]
-        adversary = adversary.detach()
-        r, m = _rmse_mse(adversary, x)
-        for model_name, target in model_transfer.items():
-            target = target.to(device=device)
-            perf[model_name]['fooling_rate'] += compute_fooling_rate(model=target, adversary=adversary,
-                                                                     clean=x) / num_samples
-            perf[model_name]['rmse'] += r / num_samples
-            perf[model_name]['mse'] += m / num_samples
+    with engine.classifier_batch_bucket(_loader_batch_size(data)):       # the last batch is usually smaller
+        for i, (x, y) in enumerate(data):
+            if i % world != rank:
+                continue
+            x, y = x.to(device=device), y.to(device=device)
+            adversary = attack(x, y)
+            if isinstance(adversary, tuple):
+                adversary = adversary[0]
+            adversary = adversary.detach()
+            r, m = _rmse_mse(adversary, x)
+            for model_name, target in model_transfer.items():
+                target = target.to(device=device)
+                perf[model_name]['fooling_rate'] += compute_fooling_rate(model=target, adversary=adversary,
+                                                                         clean=x) / num_samples
+                perf[model_name]['rmse'] += r / num_samples
+                perf[model_name]['mse'] += m / num_samples
     if world > 1:
         keys = [(name, k) for name in perf for k in ('fooling_rate', 'rmse', 'mse')]
         for (name, k), v in zip(keys, _sum_over_ranks([perf[n][k] for n, k in keys], device)):
@@ -151,8 +160,7 @@ def _rmse_mse(adversary, clean):
 
 
 def compute_fooling_rate(model, adversary, clean, reduction='sum'):
-    with torch.no_grad():
-        different = model.eval()(clean).argmax(dim=1) != model.eval()(adversary).argmax(dim=1)
+    different = engine.predict(model.eval(), clean) != engine.predict(model.eval(), adversary)
     return different.float().sum().item() if reduction == 'sum' else different.float().mean().item()
 
 

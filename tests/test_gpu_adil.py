@@ -640,3 +640,40 @@ def test_cached_pseudo_labels_match_the_golden_runs(method, tmp_path):
     steps_total = sum(len(e) for e in common["epoch_batches"][:len(l0) * (1 if method == "gd" else 2 * common.get("steps_in", 1))])
     first_epoch = len(common["epoch_batches"][0])
     assert n0 == 2 * steps_total and n1 == steps_total + first_epoch, (n0, n1, steps_total, first_epoch)
+
+
+def test_classifier_batch_bucket_leaves_the_attack_unchanged(tmp_path):
+    """engine.classifier_batch_bucket: the frozen classifier only sees batches rounded up to the bucket (zero rows
+    appended, their logits / gradients dropped); predictions, input gradients and a whole DDrague attack on a ragged
+    batch are the same as without it, and the classifier really ran at the bucket size."""
+    from attacks import ADIL
+    from dl_attack_on_imagenet_amd import engine
+    from tinynet import make_tinynet
+    net = make_tinynet(6).to(DEV)
+    sizes = []
+    hook = net.register_forward_hook(lambda m, inp, out: sizes.append(inp[0].shape[0]))
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand(5, 3, 32, 32, generator=g).to(DEV)
+    lab = engine.predict(net, x)
+    out0, ls0, g0 = engine.input_gradient(net, x, lab, "ce", -1.0, 50.0, "mean")
+    with engine.classifier_batch_bucket(8):
+        sizes.clear()
+        assert torch.equal(engine.predict(net, x), lab)
+        out1, ls1, g1 = engine.input_gradient(net, x, lab, "ce", -1.0, 50.0, "mean")
+        assert sizes == [8, 8] and out1.shape == out0.shape and g1.shape == g0.shape
+    close(out1, out0, 1e-6); close(g1, g0, 1e-7 + 1e-5 * float(g0.abs().max())); close(ls1, ls0, 1e-6)
+    sizes.clear()
+    engine.predict(net, x)
+    assert sizes == [5]                                                    # switched off again
+    d = (-1 + 2 * torch.rand(3, 32, 32, 6, generator=g)).to(DEV)
+    torch.save([d.cpu(), torch.zeros(1), [], [], torch.tensor(0.)], os.path.join(tmp_path, "ImageNet_bk.bin"))
+    atk = ADIL(net, eps=0.1, n_atoms=6, attack="supervised", model_name="bk", loss="logits", steps_inference=12,
+               dict_dir=str(tmp_path))
+    plain = atk(x, lab)
+    with engine.classifier_batch_bucket(8):
+        sizes.clear()
+        bucketed = atk(x, lab)
+    assert set(sizes) == {8}
+    close(bucketed, plain, 1e-6)
+    assert torch.equal(engine.predict(net, bucketed), engine.predict(net, plain))
+    hook.remove()
