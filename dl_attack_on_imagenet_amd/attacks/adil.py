@@ -65,6 +65,9 @@ class ADIL(Attack):
       cache_labels   learners: compute the clean pseudo-label of an image once (first epoch) instead of in every epoch
                      (engine.LabelCache; saves one of the two classifier forwards per step; default False = the
                      reference's op sequence)
+      val_every      validate (100 AdamW iterations per validation batch, adil.py:199-205) every this many epochs; the
+                     reference does it after EVERY epoch but only prints the value and stores the last one, so any
+                     setting writes the same dictionary file; 0 = after the last epoch only.  Default 1 (as upstream)
       use_graph      replay the learning step (engine.DictionaryLearner.step_graphed) and the DDrague inference iterations
                      (engine.DDragueSolver.run, three per launch) as hipGraph launches: for launch-bound uses — small
                      batches, the one-image attack of main.py; default: $ADIL_GRAPH == "1"
@@ -76,7 +79,7 @@ class ADIL(Attack):
                  data_train=None, data_val=None, trials=10, attack='supervised', model_name=None, step_size=0.01,
                  is_distributed=False, steps_in=None, loss='ce', method='gd', warm_start=False, kappa=50,
                  steps_inference=30, alpha=None, init_d=None, init_v=None, epoch_batches=None, val_batches=None,
-                 stream_dtype=None, dict_dir='trained_dicts', shuffle_seed=0, use_graph=None, cache_labels=False):
+                 stream_dtype=None, dict_dir='trained_dicts', shuffle_seed=0, use_graph=None, cache_labels=False, val_every=1):
         super().__init__("ADIL", model.eval())
         self.norm = norm.lower()
         self.eps = eps
@@ -100,6 +103,7 @@ class ADIL(Attack):
         self._shuffle_seed = int(shuffle_seed)
         self._use_graph = (os.environ.get("ADIL_GRAPH") == "1") if use_graph is None else bool(use_graph)
         self._cache_labels = bool(cache_labels)
+        self._val_every = int(val_every)
         self._pinv = None
         self._solvers = {}
         self._dict_mtime = None
@@ -168,6 +172,9 @@ class ADIL(Attack):
         for rows, (index, x) in zip(order, train.batches(order)):
             yield index, x, (train._label_cache.get(self.model, x, index, rows) if self._cache_labels and len(rows) else None)
 
+    def _val_due(self, iteration):
+        return self._val_every > 0 and (iteration + 1) % self._val_every == 0
+
     def _validate(self, val, epoch, d, batch_size):
         """Per-epoch validation through forward_supervised_AdamW in 'train' mode (adil.py:199-205).
         `val` is a ResidentImages (or None)."""
@@ -201,6 +208,7 @@ class ADIL(Attack):
 
         loss_all, fooling_rate_all = [], []
         val_fool = torch.zeros((), device=self.device)
+        validated = True
         for iteration in range(int(self.steps)):
             loss_full = torch.zeros((), dtype=torch.float32, device=self.device)
             fooled = torch.zeros((), dtype=torch.int64, device=self.device)
@@ -214,10 +222,14 @@ class ADIL(Attack):
             loss_all.append(loss_full.item() / n_img)                                      # adil.py:194
             fooling_rate_all.append(fooled.item() / n_img)                                 # adil.py:195
             print(loss_all[-1], fooling_rate_all[-1])
-            val_fool = self._validate(val_res, iteration, learner.d, batch_size)
-            print(float(val_fool))
+            validated = self._val_due(iteration)
+            if validated:
+                val_fool = self._validate(val_res, iteration, learner.d, batch_size)
+                print(float(val_fool))
             if iteration > 1 and abs(loss_all[iteration] - loss_all[iteration - 1]) < 1e-6:    # adil.py:207
                 break
+        if loss_all and not validated:                                   # the stored value is the last epoch's
+            val_fool = self._validate(val_res, len(loss_all) - 1, learner.d, batch_size)
         self._save(learner.d, learner.v, loss_all, fooling_rate_all, val_fool)
         return learner
 
@@ -236,6 +248,7 @@ class ADIL(Attack):
                                     lr_d=2 * self.step_size, lr_v=self.step_size)           # adil.py:250-251
         loss_all, fooling_rate_all = [], []
         val_fool = torch.zeros((), device=self.device)
+        validated = True
         epoch = 0
         for iteration in range(int(self.steps // self.steps_inner)):
             for _ in range(self.steps_inner):                                              # V-steps, adil.py:265-289
@@ -252,9 +265,13 @@ class ADIL(Attack):
             loss_all.append(ls.item() / n_img)               # last batch only — reference quirk Q11 (adil.py:313-317)
             fooling_rate_all.append(fooled.item() / n_img)
             print('d_step: ', loss_all[-1], fooling_rate_all[-1])
-            val_fool = self._validate(val_res, iteration, learner.d, batch_size)
+            validated = self._val_due(iteration)
+            if validated:
+                val_fool = self._validate(val_res, iteration, learner.d, batch_size)
             if iteration > 1 and abs(loss_all[iteration] - loss_all[iteration - 1]) < 1e-6:    # adil.py:329
                 break
+        if loss_all and not validated:
+            val_fool = self._validate(val_res, len(loss_all) - 1, learner.d, batch_size)
         self._save(learner.d, learner.v, loss_all, fooling_rate_all, val_fool)
         return learner
 
@@ -288,8 +305,21 @@ class ADIL(Attack):
         v = self.projection_v(v0.to(device=self.device, dtype=torch.float32))
         learner = self._learner_cls(d, v, self.eps, self.step_size, self.loss, self.targeted, self.kappa,
                                     reducer=reducer)
+        def validate(epoch):
+            """Sharded validation (adil.py:199-205): every rank solves the codes of the images it owns, counts are summed."""
+            if self._val_batches is not None:
+                vorder = self._val_batches[epoch]
+            else:
+                vorder = global_epoch_batches(len(val), batch_size, world, self._shuffle_seed + 1, epoch)
+            vfooled = torch.zeros((), dtype=torch.int64, device=self.device)
+            for gb in vorder:
+                mine = [i - vlo for i in owned_rows(gb, vlo, vhi)]
+                vfooled += engine_solve_codes(self, val_res.gather(mine), learner.d, mean_over=len(gb))
+            return torch.tensor(reducer.sum_scalars(vfooled)[0] / len(val), device=self.device)
+
         loss_all, fooling_rate_all = [], []
         val_fool = torch.zeros((), device=self.device)
+        validated = True
         for iteration in range(int(self.steps)):
             loss_full = torch.zeros((), dtype=torch.float32, device=self.device)
             fooled = torch.zeros((), dtype=torch.int64, device=self.device)
@@ -307,18 +337,13 @@ class ADIL(Attack):
             fooling_rate_all.append(tot_fooled / n_img)
             if rank == 0:
                 print(loss_all[-1], fooling_rate_all[-1])
-            if val_res is not None:
-                if self._val_batches is not None:
-                    vorder = self._val_batches[iteration]
-                else:
-                    vorder = global_epoch_batches(len(val), batch_size, world, self._shuffle_seed + 1, iteration)
-                vfooled = torch.zeros((), dtype=torch.int64, device=self.device)
-                for gb in vorder:
-                    mine = [i - vlo for i in owned_rows(gb, vlo, vhi)]
-                    vfooled += engine_solve_codes(self, val_res.gather(mine), learner.d, mean_over=len(gb))
-                val_fool = torch.tensor(reducer.sum_scalars(vfooled)[0] / len(val), device=self.device)
+            validated = self._val_due(iteration)
+            if val_res is not None and validated:
+                val_fool = validate(iteration)
             if iteration > 1 and abs(loss_all[iteration] - loss_all[iteration - 1]) < 1e-6:
                 break
+        if val_res is not None and loss_all and not validated:
+            val_fool = validate(len(loss_all) - 1)
         counts = [shard_bounds(n_img, r, world)[1] - shard_bounds(n_img, r, world)[0] for r in range(world)]
         v_all = reducer.gather_rows(learner.v, counts)                           # once, at the end (not in the data path)
         if rank == 0:

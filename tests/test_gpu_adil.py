@@ -677,3 +677,30 @@ def test_classifier_batch_bucket_leaves_the_attack_unchanged(tmp_path):
     close(bucketed, plain, 1e-6)
     assert torch.equal(engine.predict(net, bucketed), engine.predict(net, plain))
     hook.remove()
+
+
+def test_val_every_writes_the_same_dictionary_file(tmp_path):
+    """ADIL(val_every=0): validation (100 AdamW iterations per validation batch) after the last epoch only instead of
+    after every epoch.  The reference only prints the per-epoch value and stores the last one (adil.py:199-210), so the
+    dictionary file is the same — and equal to golden G7 — while the classifier runs a fraction of the forwards."""
+    from attacks import ADIL
+    z = load_golden("g7_learn_a")
+    net = net_on_gpu(z)
+    calls = {"n": 0}
+    hook = net.register_forward_hook(lambda *a: calls.__setitem__("n", calls["n"] + 1))
+    files, counts = [], []
+    for every in (1, 0, 2):
+        calls["n"] = 0
+        atk = ADIL(net, eps=float(z["logits_eps"]), steps=int(z["steps"]), norm="linf", n_atoms=int(z["k"]),
+                   batch_size=int(z["batch_size"]), data_train=IndexedTensorDataset(t(z["images"])),
+                   data_val=IndexedTensorDataset(t(z["val"])), model_name=f"ve{every}", step_size=float(z["step_size"]),
+                   loss="logits", method="gd", kappa=float(z["kappa"]), init_d=t(z["logits_d0"]), init_v=t(z["logits_v0raw"]),
+                   epoch_batches=z["logits_batches"].tolist(), val_batches=z["logits_val_batches"].tolist(),
+                   dict_dir=str(tmp_path), val_every=every)
+        files.append(torch.load(atk.model_file, map_location="cpu"))
+        counts.append(calls["n"])
+    hook.remove()
+    for d, v, loss_all, fool, val_fool in files[1:]:
+        assert torch.equal(d, files[0][0]) and torch.equal(v, files[0][1]) and loss_all == files[0][2] and fool == files[0][3]
+        assert float(val_fool) == float(files[0][4]) == float(z["logits_val_fool"])
+    assert counts[1] < counts[2] < counts[0]
