@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
 // then plain / transposed bf16 LDS reads, exactly as in the bf16 kernel, three planes each.  32-pixel tiles, two
 // tiles in flight in two register stages; 256 rows per launch (LDS: planes of 256 x 32 px = 60 KB + D 30 KB + 32 KB).
 // =========================================================================================================== //
-template <int AT, int NW, bool ACC>
+template <int AT, int NW, bool ACC, bool WV = true>
 __global__ __launch_bounds__(NW * 64) void grad_fused_f32_kernel(const float* __restrict__ g, const float* __restrict__ d,
                                                                  const float* __restrict__ vpt, int vstride,
                                                                  float* __restrict__ grad_d, float* __restrict__ slab, int B,
@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_f32_kernel(const float* __
     static_assert(NW % NTILE == 0 && KS > 1 && 16 % KS == 0, "row splits must divide the 16 accumulator registers");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sdt = reinterpret_cast<bf16_t*>(smem_raw);           // [2][3][KA][GD]
-    bf16_t* simg = sdt + 2 * DBUF;                               // [3][NW*32][GI]
+    bf16_t* simg = sdt + (WV ? 2 * DBUF : 0);                    // [3][NW*32][GI]   (WV = false: grad_d alone, no D tile)
     float* red = reinterpret_cast<float*>(simg + 3 * IPL);       // [NW][16][64]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int t0 = blockIdx.x * tiles_per_wg;
@@ -1298,11 +1298,13 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_f32_kernel(const float* __
     const bool active = b0 < Bp;
     const int lrow = lane / LPR, lcol = (lane - lrow * LPR) * 4;
 
-    f32x16 accv[AT];
+    f32x16 accv[WV ? AT : 1];
+    if constexpr (WV) {
 #pragma unroll
-    for (int at = 0; at < AT; ++at)
+        for (int at = 0; at < AT; ++at)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accv[at][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) accv[at][r] = 0.0f;
+    }
 
     Frag vfr[NKG];                                               // codes of this wave's row split, split once
 #pragma unroll
@@ -1313,13 +1315,15 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_f32_kernel(const float* __
 #pragma unroll
     for (int kg = 0; kg < NKG; ++kg) M::touch(vfr[kg]);          // retired before the loop (see the generic kernel)
 
-    struct Stage { float dreg[DPT]; u32x4 blk[NLD]; };
+    struct Stage { float dreg[WV ? DPT : 1]; u32x4 blk[NLD]; };
     auto load_stage = [&](Stage& st, int tile) __attribute__((always_inline)) {
+        if constexpr (WV) {
 #pragma unroll
-        for (int e = 0; e < DPT; ++e) {                           // raw loads, clamped addresses (masked when written)
-            const int i = tid + e * NT;
-            const int px = i / KA, a = i - px * KA;
-            st.dreg[e] = d[(size_t)(tile * TW + (px < TW ? px : TW - 1)) * K + (a < K ? a : K - 1)];
+            for (int e = 0; e < DPT; ++e) {                       // raw loads, clamped addresses (masked when written)
+                const int i = tid + e * NT;
+                const int px = i / KA, a = i - px * KA;
+                st.dreg[e] = d[(size_t)(tile * TW + (px < TW ? px : TW - 1)) * K + (a < K ? a : K - 1)];
+            }
         }
         if (active) {
 #pragma unroll
@@ -1330,11 +1334,13 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_f32_kernel(const float* __
         }
     };
     auto write_d = [&](bf16_t* dst, const Stage& st) __attribute__((always_inline)) {
+        if constexpr (WV) {
 #pragma unroll
-        for (int e = 0; e < DPT; ++e) {
-            const int i = tid + e * NT;
-            const int px = i / KA, a = i - px * KA;
-            if (px < TW) DImg<float>::put(dst, a * GD + px, DPL, st.dreg[e] * ((a < K) ? 1.0f : 0.0f));
+            for (int e = 0; e < DPT; ++e) {
+                const int i = tid + e * NT;
+                const int px = i / KA, a = i - px * KA;
+                if (px < TW) DImg<float>::put(dst, a * GD + px, DPL, st.dreg[e] * ((a < K) ? 1.0f : 0.0f));
+            }
         }
     };
     Stage sa, sb;
@@ -1361,7 +1367,7 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_f32_kernel(const float* __
         }
         if (tile + 2 < t1) load_stage(cur, tile + 2);
         lds_barrier();                                          // all image planes + D[dbuf] visible
-        if (active) {                                             // ---- grad_v: rows of this wave, all 32 pixels
+        if (WV && active) {                                       // ---- grad_v: rows of this wave, all 32 pixels
             const bf16_t* sdb = sdt + dbuf * DBUF;
 #pragma unroll
             for (int g3 = 0; g3 < TW / 16; ++g3) {
@@ -1408,7 +1414,7 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_f32_kernel(const float* __
         tile_step(tile, 0, sa, sb);
         if (tile + 1 < t1) tile_step(tile + 1, 1, sb, sa);
     }
-    if (active) {
+    if (WV && active) {
         float* dst = slab + (size_t)blockIdx.x * Bp * K;
 #pragma unroll
         for (int at = 0; at < AT; ++at)
@@ -1750,16 +1756,22 @@ static int launch_grad_v(const T* g, const float* d, float* grad_vb, int B, int 
     const int nwg_fast = nfast > 0 ? (nfast + tpw_fast - 1) / tpw_fast : 0;
     const int tpw_slow = nslow > 0 ? (nslow + kNumCU - 1) / kNumCU : 1;
     const int nwg_slow = nslow > 0 ? (nslow + tpw_slow - 1) / tpw_slow : 0;
-    if constexpr (sizeof(T) == 4 && AT <= 2) {
-        if (vec && P % 32 == 0) {                                 // fp32 streams: planes split once, 512 rows per launch
+    if constexpr (sizeof(T) == 4) {
+        if (vec && P % 32 == 0) {             // fp32 streams: planes split once; 512 rows per launch (K > 64: 256, the D planes double)
+            constexpr int kRows = AT <= 2 ? 512 : 256;
             const int nt = P / 32, tpw = (nt + kNumCU - 1) / kNumCU, nwg = (nt + tpw - 1) / tpw;
-            for (int r0 = 0; r0 < Bp; r0 += 512) {
-                const int rows_p = imin(Bp - r0, 512), rows = imin(B - r0, rows_p);
+            for (int r0 = 0; r0 < Bp; r0 += kRows) {
+                const int rows_p = imin(Bp - r0, kRows), rows = imin(B - r0, rows_p);
                 const float* gc = (const float*)g + (size_t)r0 * P;
                 int rc;
-                if (rows_p > 256) rc = launch_grad_v_f32_nw<AT, 16>(gc, d, slab, rows, rows_p, P, K, nt, tpw, nwg, st);
-                else if (rows_p > 128) rc = launch_grad_v_f32_nw<AT, 8>(gc, d, slab, rows, rows_p, P, K, nt, tpw, nwg, st);
-                else rc = launch_grad_v_f32_nw<AT, 4>(gc, d, slab, rows, rows_p, P, K, nt, tpw, nwg, st);
+                if constexpr (AT <= 2) {
+                    if (rows_p > 256) rc = launch_grad_v_f32_nw<AT, 16>(gc, d, slab, rows, rows_p, P, K, nt, tpw, nwg, st);
+                    else if (rows_p > 128) rc = launch_grad_v_f32_nw<AT, 8>(gc, d, slab, rows, rows_p, P, K, nt, tpw, nwg, st);
+                    else rc = launch_grad_v_f32_nw<AT, 4>(gc, d, slab, rows, rows_p, P, K, nt, tpw, nwg, st);
+                } else {
+                    if (rows_p > 128) rc = launch_grad_v_f32_nw<AT, 8>(gc, d, slab, rows, rows_p, P, K, nt, tpw, nwg, st);
+                    else rc = launch_grad_v_f32_nw<AT, 4>(gc, d, slab, rows, rows_p, P, K, nt, tpw, nwg, st);
+                }
                 if (rc) return rc;
                 hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows_p * K + 63) / 64), dim3(256), 0, st, (const float*)slab,
                                    nwg, rows_p, K, rows, K, grad_vb + (size_t)r0 * K);
@@ -1953,6 +1965,35 @@ static int launch_grad_d_lds(const T* g, const float* vp, float* grad_d, int B, 
     return 0;
 }
 
+// ---- grad_d alone, fp32 streams, K > 64: the grad_d half of grad_fused_f32_kernel (pre-split operands), 256 rows per launch -- //
+template <int AT>
+static int launch_grad_d_f32_lds(const float* g, const float* vp, float* grad_d, int B, int P, int K, int accumulate_d, void* ws,
+                                 hipStream_t st) {
+    constexpr int KA = AT * 32, NW = 8, TW = 32;
+    const int Kp = round_up(K, 16), Bp = round_up(B, 32);
+    float* vpt = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL((transpose_codes_kernel<float>), dim3((KA * Bp + 255) / 256), dim3(256), 0, st, vp, Bp, Kp, KA, vpt);
+    ADIL_CHECK_LAUNCH();
+    const int nt = P / TW, tpw = (nt + kNumCU - 1) / kNumCU, nwg = (nt + tpw - 1) / tpw;
+    const size_t lds = 3 * (size_t)NW * 32 * (TW + DPAD) * sizeof(bf16_t) + (size_t)NW * 16 * 64 * sizeof(float);
+    int rc = set_lds((const void*)grad_fused_f32_kernel<AT, NW, false, false>, lds);
+    if (rc) return rc;
+    rc = set_lds((const void*)grad_fused_f32_kernel<AT, NW, true, false>, lds);
+    if (rc) return rc;
+    for (int r0 = 0; r0 < Bp; r0 += NW * 32) {
+        const int rows_p = imin(Bp - r0, NW * 32), rows = imin(B - r0, rows_p);
+        const float* gc = g + (size_t)r0 * P;
+        if (accumulate_d || r0 > 0)
+            hipLaunchKernelGGL((grad_fused_f32_kernel<AT, NW, true, false>), dim3(nwg), dim3(NW * 64), lds, st, gc,
+                               (const float*)nullptr, (const float*)vpt + r0, Bp, grad_d, (float*)nullptr, rows, rows_p, P, K, nt, tpw);
+        else
+            hipLaunchKernelGGL((grad_fused_f32_kernel<AT, NW, false, false>), dim3(nwg), dim3(NW * 64), lds, st, gc,
+                               (const float*)nullptr, (const float*)vpt + r0, Bp, grad_d, (float*)nullptr, rows, rows_p, P, K, nt, tpw);
+        ADIL_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 template <typename T, int PXT, int AT>
 static int launch_grad_cfg(const T* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P,
                            int K, int accumulate_d, void* ws, hipStream_t st) {
@@ -1977,6 +2018,13 @@ static int launch_grad_cfg(const T* g, const float* d, const float* vp, float* g
     }
     if constexpr (AT == 4 && sizeof(T) == 2) {
         if (grad_d != nullptr) rc = launch_grad_d_lds<T, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, st);
+    } else if constexpr (AT == 4 && sizeof(T) == 4) {
+        if (grad_d != nullptr) {
+            if (P % 32 == 0 && (uintptr_t)g % 16 == 0)
+                rc = launch_grad_d_f32_lds<AT>((const float*)g, vp, grad_d, B, P, K, accumulate_d, ws, st);
+            else
+                rc = launch_grad_d<T, PXT, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, st);
+        }
     } else {
         if (grad_d != nullptr) rc = launch_grad_d<T, PXT, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, st);
     }

@@ -675,3 +675,30 @@ def test_grad_bf16_many_atoms(b, k, c, h, w):
     acc = gd_only.clone()
     ops().grad(g, d, vp, b, want_v=False, grad_d=acc, accumulate_d=True)
     close(acc, 2 * gd_only, 1e-5 * b ** 0.5 * 8)
+
+
+@pytest.mark.parametrize("b,k,c,h,w", [(512, 100, 3, 32, 32), (300, 65, 3, 16, 24), (130, 128, 3, 16, 16), (40, 100, 3, 8, 8),
+                                       (257, 100, 3, 9, 7)])
+def test_grad_fp32_many_atoms(b, k, c, h, w):
+    """K > 64 on fp32 streams: grad_d alone through the pre-split kernel (grad_fused_f32_kernel without its grad_v half,
+    256 rows per launch, the second chunk accumulates) and grad_v through grad_v_f32_kernel<4> — or the generic kernels
+    when the rows are not whole 32-pixel tiles (9x7).  fp32-grade tolerances against fp64 matmuls, reproducible."""
+    gen = torch.Generator().manual_seed(b + k + h + 5)
+    d = (-1 + 2 * torch.rand(c, h, w, k, generator=gen)).to(DEV)
+    v = (torch.randn(b, k, generator=gen) * 0.02).to(DEV)
+    g = torch.randn(b, c, h, w, generator=gen).to(DEV)
+    p = c * h * w
+    vp = ops().pack_codes(v, None, b)
+    gd, gvb = ops().grad(g, d, vp, b)
+    g2 = g.double().reshape(b, p)
+    rd, rv = g2.t() @ v.double(), g2 @ d.double().reshape(p, k)
+    close(gd.reshape(p, k), rd, 2e-6 * b ** 0.5 * 4)
+    close(gvb, rv, 3e-6 * p ** 0.5 * 4)
+    gd_only, _ = ops().grad(g, d, vp, b, want_v=False)
+    _, gv_only = ops().grad(g, d, None, b, want_d=False)
+    assert torch.equal(gd, gd_only) and torch.equal(gvb, gv_only)
+    gd2, gvb2 = ops().grad(g, d, vp, b)
+    assert torch.equal(gd, gd2) and torch.equal(gvb, gvb2)
+    acc = gd.clone()
+    ops().grad(g, d, vp, b, grad_d=acc, accumulate_d=True)
+    close(acc, 2 * gd, 2e-6 * b ** 0.5 * 8)
