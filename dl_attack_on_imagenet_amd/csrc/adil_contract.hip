@@ -470,7 +470,7 @@ __device__ __forceinline__ void synth_store_buf(const f32x16 (&acc)[4], buf_rsrc
 // for its codes (hidden under the HBM latency of x) instead of one per k-group in the MFMA loop.
 // HOIST = 4 covers K <= 64; K > 64 runs the HOIST = 8 instantiation (all k-groups up front; costs ~45 registers, i.e. one
 // resident workgroup per CU less, which the K <= 64 stream cannot afford)
-template <typename T, typename O, bool XACC, int HOIST>
+template <typename T, typename O, bool XACC, int HOIST, int NWV = 4>
 __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const float* __restrict__ vp,
                                                 T* __restrict__ out, const typename DImg<O>::Elem* sd, int B, int P,
                                                 int Kp, int Ks, int p0, float delta_clamp, int pixel_clamp, int w, int c,
@@ -483,7 +483,7 @@ __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const f
     const int nbb = (B + 31) >> 5;
     const unsigned rowb = (unsigned)P * (unsigned)sizeof(T);
     const int voff = (int)((unsigned)(4 * h) * rowb) + (p0 + 4 * c) * (int)sizeof(T);
-    for (int bb = w; bb < nbb; bb += 4) {
+    for (int bb = w; bb < nbb; bb += NWV) {
         const int b0 = bb << 5;
         const int rows = B - b0 < 32 ? B - b0 : 32;
         const buf_rsrc rx = block_rsrc(x ? x + (size_t)b0 * P : nullptr, x ? (unsigned)rows * rowb : 0u);
@@ -548,7 +548,7 @@ __device__ __forceinline__ void synth_sweep_buf(const T* __restrict__ x, const f
 
 // The 128-pixel slice of the dictionary operand (D for synth, D_dagger^T for the z-step) -> LDS planes of DImg<T>,
 // tile-major rows (pixel r at row (r&3)*32 + (r>>2)), padded atoms zeroed.  256 threads.
-template <typename T, bool FAST>
+template <typename T, bool FAST, int NT = 256>
 __device__ __forceinline__ void fill_dict_slice(const float* __restrict__ d, typename DImg<T>::Elem* sd, int p0, int P, int K,
                                                 int Kp, int Ks, int tid, float dscale = 1.0f) {
     using DI = DImg<T>;
@@ -562,16 +562,16 @@ __device__ __forceinline__ void fill_dict_slice(const float* __restrict__ d, typ
         const float4* src = reinterpret_cast<const float4*>(d + (size_t)p0 * K);
         const int nq = 32 * K;
         const float rk = 1.0f / (float)K;
-        for (int q0 = tid; q0 < nq; q0 += 256 * 8) {
+        for (int q0 = tid; q0 < nq; q0 += NT * 8) {
             float4 val[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int q = q0 + 256 * u;
+                const int q = q0 + NT * u;
                 val[u] = src[q < nq ? q : nq - 1];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int q = q0 + 256 * u;
+                const int q = q0 + NT * u;
                 if (q < nq) {
                     const int i = 4 * q;
                     int r = (int)(((float)i + 0.5f) * rk);           // i / K, exact: |error| << 0.5 / K for i < 2^14
@@ -599,15 +599,16 @@ __device__ __forceinline__ void fill_dict_slice(const float* __restrict__ d, typ
                 }
             }
         }
+        if (NT == 256 || tid < 256)
         for (int k = K + (tid & 1); k < Kp; k += 2)                   // zero the padded atoms of row tid/2
             DI::put(sd, (((tid >> 1) & 3) * 32 + (tid >> 3)) * Ks + k, plane, 0.0f);
     } else {
         // element-wise fill with pixel / atom guards: eight independent loads are issued before the first conversion
-        for (int i0 = tid; i0 < SYNTH_TILE * Kp; i0 += 256 * 8) {
+        for (int i0 = tid; i0 < SYNTH_TILE * Kp; i0 += NT * 8) {
             float val[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = i0 + 256 * u;
+                const int i = i0 + NT * u;
                 const int r = i / Kp, k = i - r * Kp;
                 const int p = p0 + r;
                 const float ok = ((p < P) && (k < K)) ? 1.0f : 0.0f;
@@ -615,7 +616,7 @@ __device__ __forceinline__ void fill_dict_slice(const float* __restrict__ d, typ
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = i0 + 256 * u;
+                const int i = i0 + NT * u;
                 const int r = i / Kp, k = i - r * Kp;
                 DI::put(sd, ((r & 3) * 32 + (r >> 2)) * Ks + k, plane, M::SCALED ? val[u] * dscale : val[u]);
             }
@@ -623,8 +624,8 @@ __device__ __forceinline__ void fill_dict_slice(const float* __restrict__ d, typ
     }
 }
 
-template <typename T, typename O, bool XACC, bool FAST, int HOIST = 4>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void synth_mfma_kernel(const T* __restrict__ x, const float* __restrict__ d,
+template <typename T, typename O, bool XACC, bool FAST, int HOIST = 4, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV == 4 ? 3 : 2))) void synth_mfma_kernel(const T* __restrict__ x, const float* __restrict__ d,
                                                          const float* __restrict__ vp, T* __restrict__ out, int B,
                                                          int P, int K, int Kp, float delta_clamp, int pixel_clamp,
                                                          int tile0, OpScale sc) {
@@ -637,10 +638,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
     // consecutive tiles go to consecutive workgroups, i.e. round-robin over the 8 XCDs: for this pure stream that is
     // 8 % faster than giving each XCD one contiguous range of tiles (measured)
     const int p0 = (tile0 + blockIdx.x) * SYNTH_TILE;
-    fill_dict_slice<O, FAST>(d, sd, p0, P, K, Kp, Ks, tid, sc.d);
+    fill_dict_slice<O, FAST, NWV * 64>(d, sd, p0, P, K, Kp, Ks, tid, sc.d);
     __syncthreads();
     if constexpr (FAST)
-        synth_sweep_buf<T, O, XACC, HOIST>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp,
+        synth_sweep_buf<T, O, XACC, HOIST, NWV>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp,
                                     __builtin_amdgcn_readfirstlane(w), c, h, sc);
     else
         synth_sweep<T, O, XACC, FAST>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp, w, c, h, sc);
@@ -666,8 +667,8 @@ __device__ __forceinline__ float zstep_quad(float (&zv)[4], float (&mv)[4], floa
     return dmax;
 }
 
-template <bool FAST>
-__global__ __launch_bounds__(256) void zstep_mfma_kernel(float* __restrict__ z, float* __restrict__ m,
+template <bool FAST, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void zstep_mfma_kernel(float* __restrict__ z, float* __restrict__ m,
                                                          float* __restrict__ sq, const float* __restrict__ d,
                                                          const float* __restrict__ vp, int B, int P, int K, int Kp,
                                                          AdamWHyper hy, float lo, float hi, float* max_abs_delta,
@@ -693,7 +694,7 @@ __global__ __launch_bounds__(256) void zstep_mfma_kernel(float* __restrict__ z, 
     const int plane = SYNTH_TILE * Ks;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int p0 = (tile0 + blockIdx.x) * SYNTH_TILE;
-    fill_dict_slice<float, FAST>(d, sd, p0, P, K, Kp, Ks, tid);
+    fill_dict_slice<float, FAST, NWV * 64>(d, sd, p0, P, K, Kp, Ks, tid);
     __syncthreads();
     const int NG = Kp >> 4;
     const int nbb = (B + 31) >> 5;
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(256) void zstep_mfma_kernel(float* __restrict__ z, 
         // trip per row (round 1: 469 us for 1.88 GB).  Rows >= B: loads return 0, stores are dropped by the descriptor.
         const unsigned rowb = (unsigned)P * 4u;
         const int voff = (int)((unsigned)(4 * h) * rowb) + (p0 + 4 * c) * 4;
-        for (int bb = __builtin_amdgcn_readfirstlane(w); bb < nbb; bb += 4) {
+        for (int bb = __builtin_amdgcn_readfirstlane(w); bb < nbb; bb += NWV) {
             const int b0 = bb << 5;
             const int rows = B - b0 < 32 ? B - b0 : 32;
             const unsigned bytes = (unsigned)rows * rowb;
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(256) void zstep_mfma_kernel(float* __restrict__ z, 
             }
         }
     } else {
-        for (int bb = w; bb < nbb; bb += 4) {
+        for (int bb = w; bb < nbb; bb += NWV) {
             const int b0 = bb << 5;
             f32x16 acc[4];
 #pragma unroll
@@ -1618,6 +1619,16 @@ static int launch_synth_range(const void* x, const float* d, const float* vp, vo
             return 0;
         }
     }
+    if constexpr (FAST && sizeof(typename Mma<O>::Frag) > 16) {
+        if (Kp > 64) {      // fp32 operands, K > 64: 92 KB of D planes = one workgroup per CU, so give it 8 waves instead of 4
+            int rc = set_lds((const void*)synth_mfma_kernel<T, O, XACC, true, 4, 8>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((synth_mfma_kernel<T, O, XACC, true, 4, 8>), dim3(ntiles), dim3(512), lds, st, (const T*)x, d, vp,
+                               (T*)out, B, P, K, Kp, delta_clamp, pixel_clamp, tile0, sc);
+            ADIL_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     int rc = set_lds((const void*)synth_mfma_kernel<T, O, XACC, FAST>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((synth_mfma_kernel<T, O, XACC, FAST>), dim3(ntiles), dim3(256), lds, st, (const T*)x, d, vp, (T*)out,
@@ -2063,6 +2074,16 @@ static int launch_zstep_range(float* z, float* m, float* sq, const float* d, con
     if (ntiles <= 0) return 0;
     const int Kp = round_up(K, 16);
     const size_t lds = (size_t)DImg<float>::PLANES * SYNTH_TILE * (Kp + DPAD) * sizeof(bf16_t);
+    if constexpr (FAST) {
+        if (Kp > 64) {                     // 92 KB of D_dagger planes = one workgroup per CU: 8 waves instead of 4 (as synth)
+            int rc = set_lds((const void*)zstep_mfma_kernel<true, 8>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((zstep_mfma_kernel<true, 8>), dim3(ntiles), dim3(512), lds, st, z, m, sq, d, vp, B, P, K, Kp, hy, lo,
+                               hi, max_abs_delta, tile0, skip_if_below, skip_threshold, clear, dyn);
+            ADIL_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     int rc = set_lds((const void*)zstep_mfma_kernel<FAST>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((zstep_mfma_kernel<FAST>), dim3(ntiles), dim3(256), lds, st, z, m, sq, d, vp, B, P, K, Kp, hy, lo, hi,
