@@ -1527,6 +1527,87 @@ __global__ __launch_bounds__(NW * 64) void grad_v_f32_kernel(const float* __rest
     }
 }
 
+// =========================================================================================================== //
+// K7  Gram matrix D^T D (adil.py:523), K x K, fp32-grade on the bf16 matrix pipe.  The D tile of 32 pixels is staged
+// exactly as in grad_v_f32_kernel (transposed, three bf16 planes, [atom][pixel]) — and serves as BOTH MFMA operands: the
+// fragments of atom tile i (lane = atom, 8 consecutive pixels) against those of atom tile j.  8 waves share the AT x AT
+// output tiles; partial sums per workgroup, reduced in a fixed order by grad_v_reduce_kernel (bitwise reproducible).
+// Round 1-2 had a scalar-FMA kernel here: 258 us at K = 50, 3.2 ms at K = 100; this one reads D once (30 / 60 MB).
+// =========================================================================================================== //
+template <int AT>
+__global__ __launch_bounds__(512) void gram_mfma_kernel(const float* __restrict__ d, float* __restrict__ partial, int P, int K,
+                                                        int ntiles, int tiles_per_wg) {
+    using M = Mma<float>;
+    constexpr int TW = 32, KA = AT * 32, NT = 512, NW = 8;
+    constexpr int GD = TW + DPAD, DPL = KA * GD, DBUF = 3 * DPL;
+    constexpr int DPT = (TW * KA + NT - 1) / NT;
+    constexpr int NOUT = AT * AT, MAXT = (NOUT + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sdt = reinterpret_cast<bf16_t*>(smem_raw);           // [2][3][KA][GD]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    const int t0 = blockIdx.x * tiles_per_wg;
+    const int t1 = min(ntiles, t0 + tiles_per_wg);
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+    float dreg[DPT];
+    auto load_d = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) {
+            const int i = tid + e * NT;
+            const int px = i / KA, a = i - px * KA;
+            const int pix = tile * TW + (px < TW ? px : TW - 1);
+            dreg[e] = d[(size_t)(pix < P ? pix : P - 1) * K + (a < K ? a : K - 1)];
+        }
+    };
+    auto write_d = [&](bf16_t* dst, int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) {
+            const int i = tid + e * NT;
+            const int px = i / KA, a = i - px * KA;
+            const float keep = (a < K && tile * TW + px < P) ? 1.0f : 0.0f;     // atom / pixel tails: multiply, never a select
+            if (px < TW) DImg<float>::put(dst, a * GD + px, DPL, dreg[e] * keep);
+        }
+    };
+    if (t0 < t1) { load_d(t0); write_d(sdt, t0); }
+    for (int tile = t0; tile < t1; ++tile) {
+        const int buf = (tile - t0) & 1;
+        if (tile + 1 < t1) load_d(tile + 1);
+        lds_barrier();                                          // D[buf] visible; everyone is done reading D[buf^1]
+        const bf16_t* sdb = sdt + buf * DBUF;
+#pragma unroll
+        for (int q = 0; q < MAXT; ++q) {
+            const int o = w + q * NW;                             // output tile (ti, tj), wave-uniform
+            if (o < NOUT) {
+                const int ti = o / AT, tj = o - ti * AT;
+#pragma unroll
+                for (int g3 = 0; g3 < TW / 16; ++g3)
+                    M::mma(acc[q], DImg<float>::load8(sdb + (ti * 32 + c) * GD + 16 * g3 + 8 * h, DPL),
+                           DImg<float>::load8(sdb + (tj * 32 + c) * GD + 16 * g3 + 8 * h, DPL));
+            }
+        }
+        if (tile + 1 < t1) write_d(sdt + (buf ^ 1) * DBUF, tile + 1);
+    }
+    float* dst = partial + (size_t)blockIdx.x * K * K;
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) {
+        const int o = w + q * NW;
+        if (o < NOUT) {
+            const int ti = o / AT, tj = o - ti * AT;
+            const int j = tj * 32 + c;
+            if (j < K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = ti * 32 + c_row(r, h);
+                    if (i < K) dst[(size_t)i * K + j] = acc[q][r];
+                }
+            }
+        }
+    }
+}
+
 // codes transposed + converted to the MFMA element type: vpt[a][b] = vp[b][a]  (a < KA, b < Bp)
 template <typename E>
 __global__ __launch_bounds__(256) void transpose_codes_kernel(const float* __restrict__ vp, int Bp, int Kp, int KA,
@@ -1593,6 +1674,32 @@ static int launch_grad_v_f32_nw(const float* g, const float* d, float* slab, int
 
 static inline int atom_tiles(int K) { return (K + 31) / 32; }
 static inline int grad_at(int K) { const int a = atom_tiles(K); return a <= 2 ? a : 4; }       // instantiated: 1, 2, 4
+
+// ---- K7 Gram ------------------------------------------------------------------------------------------------ //
+extern "C" size_t adil_gram_workspace_bytes(int P, int K) { (void)P; return (size_t)kNumCU * K * K * sizeof(float); }
+
+template <int AT>
+static int launch_gram(const float* d, int P, int K, float* gram, float* ws, hipStream_t st) {
+    const int nt = (P + 31) / 32, tpw = (nt + kNumCU - 1) / kNumCU, nwg = (nt + tpw - 1) / tpw;
+    const size_t lds = 2 * 3 * (size_t)AT * 32 * (32 + DPAD) * sizeof(bf16_t);
+    int rc = set_lds((const void*)gram_mfma_kernel<AT>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((gram_mfma_kernel<AT>), dim3(nwg), dim3(512), lds, st, d, ws, P, K, nt, tpw);
+    ADIL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((K * K + 63) / 64), dim3(256), 0, st, (const float*)ws, nwg, K, K, K, K, gram);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_gram(const float* d, int P, int K, float* gram, void* ws, size_t ws_bytes, void* stream) {
+    ADIL_ENTER();
+    if (!d || !gram || !ws || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
+    if (ws_bytes < adil_gram_workspace_bytes(P, K)) return ADIL_EWORKSPACE;
+    const int at = grad_at(K);
+    if (at == 1) return launch_gram<1>(d, P, K, gram, (float*)ws, (hipStream_t)stream);
+    if (at == 2) return launch_gram<2>(d, P, K, gram, (float*)ws, (hipStream_t)stream);
+    return launch_gram<4>(d, P, K, gram, (float*)ws, (hipStream_t)stream);
+}
 
 extern "C" size_t adil_grad_workspace_bytes(int B, int P, int K) {
     (void)P;

@@ -308,48 +308,7 @@ __global__ __launch_bounds__(256) void atom_scale_kernel(float* __restrict__ d, 
     }
 }
 
-// ---- K7: Gram matrix partials and D * M^T ----------------------------------- //
-// Each block owns a contiguous row range; thread t owns outputs o = t, t+256, ...
-template <int MAXO>
-__global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ d, int P, int K,
-                                                           int rows_per_block, float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float srow[];   // [32][K]
-    const int KK = K * K;
-    float acc[MAXO];
-#pragma unroll
-    for (int o = 0; o < MAXO; ++o) acc[o] = 0.0f;
-    const int p_begin = blockIdx.x * rows_per_block;
-    const int p_end = min(P, p_begin + rows_per_block);
-    for (int p0 = p_begin; p0 < p_end; p0 += 32) {
-        const int nr = min(32, p_end - p0);
-        __syncthreads();
-        for (int i = threadIdx.x; i < nr * K; i += 256) srow[i] = d[(size_t)p0 * K + i];
-        __syncthreads();
-#pragma unroll
-        for (int o = 0; o < MAXO; ++o) {
-            const int oi = threadIdx.x + o * 256;
-            if (oi < KK) {
-                const int i = oi / K, j = oi - i * K;
-                float a = acc[o];
-                for (int r = 0; r < nr; ++r) a += srow[r * K + i] * srow[r * K + j];
-                acc[o] = a;
-            }
-        }
-    }
-#pragma unroll
-    for (int o = 0; o < MAXO; ++o) {
-        const int oi = threadIdx.x + o * 256;
-        if (oi < KK) partial[(size_t)blockIdx.x * KK + oi] = acc[o];
-    }
-}
-__global__ void sum_partials_kernel(const float* __restrict__ partial, int nblocks, int n, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float acc = 0.0f;
-    for (int b = 0; b < nblocks; ++b) acc += partial[(size_t)b * n + i];
-    out[i] = acc;
-}
-
+// ---- K7: D * M^T (the Gram matrix itself is an MFMA kernel: adil_gram in adil_contract.hip) ----------- //
 // out[p][k] = sum_j d[p][j] * mat[k][j]
 __global__ __launch_bounds__(256) void dict_rightmul_kernel(const float* __restrict__ d, const float* __restrict__ mat,
                                                             int P, int K, int KT, float* __restrict__ out) {
@@ -552,33 +511,6 @@ extern "C" int adil_atom_scale(float* d, int P, int K, const float* norms, int s
     const size_t n = (size_t)P * K;
     hipLaunchKernelGGL(atom_scale_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, d, n, K, norms,
                        sphere);
-    ADIL_CHECK_LAUNCH();
-    return 0;
-}
-
-static const int kGramBlocks = 256;
-extern "C" size_t adil_gram_workspace_bytes(int P, int K) { (void)P; return (size_t)kGramBlocks * K * K * sizeof(float); }
-
-extern "C" int adil_gram(const float* d, int P, int K, float* gram, void* ws, size_t ws_bytes, void* stream) {
-    ADIL_ENTER();
-    if (!d || !gram || !ws || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
-    if (ws_bytes < adil_gram_workspace_bytes(P, K)) return ADIL_EWORKSPACE;
-    const int rows_per_block = (P + kGramBlocks - 1) / kGramBlocks;
-    const int nblocks = (P + rows_per_block - 1) / rows_per_block;
-    const size_t lds = (size_t)32 * K * sizeof(float);
-    const int KK = K * K;
-    if (KK <= 256 * 4)
-        hipLaunchKernelGGL(gram_partial_kernel<4>, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, d, P, K,
-                           rows_per_block, (float*)ws);
-    else if (KK <= 256 * 16)
-        hipLaunchKernelGGL(gram_partial_kernel<16>, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, d, P, K,
-                           rows_per_block, (float*)ws);
-    else
-        hipLaunchKernelGGL(gram_partial_kernel<64>, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, d, P, K,
-                           rows_per_block, (float*)ws);
-    ADIL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((KK + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
-                       nblocks, KK, gram);
     ADIL_CHECK_LAUNCH();
     return 0;
 }

@@ -702,3 +702,17 @@ def test_grad_fp32_many_atoms(b, k, c, h, w):
     acc = gd.clone()
     ops().grad(g, d, vp, b, grad_d=acc, accumulate_d=True)
     close(acc, 2 * gd, 2e-6 * b ** 0.5 * 8)
+
+
+@pytest.mark.parametrize("k", [10, 50, 100])
+def test_gram_full_size(k):
+    """D^T D at the BASELINE image size on the MFMA kernel (gram_mfma_kernel: the transposed D tile is both operands):
+    fp32-grade against an fp64 matmul, symmetric, bitwise reproducible."""
+    gen = torch.Generator().manual_seed(k)
+    d = (-1 + 2 * torch.rand(3, 224, 224, k, generator=gen)).to(DEV)
+    gm = ops().gram(d)
+    d2 = d.double().reshape(-1, k)
+    ref = d2.t() @ d2
+    close(gm, ref, 3e-6 * float(ref.abs().max()))
+    close(gm, gm.t(), 3e-6 * float(ref.abs().max()))
+    assert torch.equal(gm, ops().gram(d))
