@@ -153,7 +153,8 @@ int adil_atom_norms(const float* d, int P, int K, float* norms, void* ws, size_t
 /* Per-atom scaling: d[:,k] /= (sphere ? norms[k] : max(norms[k], 1))   (utils.py:49-54). */
 int adil_atom_scale(float* d, int P, int K, const float* norms, int sphere, void* stream);
 
-/* Gram matrix  gram (K x K) = D^T D   (adil.py:523). ws: adil_atom_workspace_bytes(P, K*K)… see .hip */
+/* Gram matrix  gram (K x K) = D^T D   (adil.py:523), fp32-grade on the matrix pipe (split bf16 MFMAs), bitwise
+ * reproducible.  ws: adil_gram_workspace_bytes(P, K) bytes of device scratch (per-workgroup partial sums). */
 size_t adil_gram_workspace_bytes(int P, int K);
 int adil_gram(const float* d, int P, int K, float* gram, void* ws, size_t ws_bytes, void* stream);
 
