@@ -88,9 +88,16 @@ def _padded_rows(x: Tensor) -> Tensor:
     return torch.cat([x, pad])
 
 
+def _classify(model, x: Tensor) -> Tensor:
+    """Logits of the rows of x (the classifier itself may see zero rows appended, see classifier_batch_bucket)."""
+    xp = _padded_rows(x)
+    out = model(xp)
+    return out if xp is x else out[:x.shape[0]]
+
+
 @torch.no_grad()
 def predict(model, x: Tensor) -> Tensor:
-    return model(_padded_rows(x))[:x.shape[0]].argmax(dim=-1)
+    return _classify(model, x).argmax(dim=-1)
 
 
 def input_gradient(model, xt: Tensor, labels: Tensor, loss: str, coeff: float, kappa: float,
@@ -99,7 +106,7 @@ def input_gradient(model, xt: Tensor, labels: Tensor, loss: str, coeff: float, k
     classifier's weight gradients (the reference computes and discards them, quirk Q8)."""
     xt = xt.detach().requires_grad_(True)
     with torch.enable_grad():
-        out = model(_padded_rows(xt))[:xt.shape[0]]
+        out = _classify(model, xt)
         ls = attack_loss(out, labels, loss, coeff, kappa, ce_reduction)
         (g,) = torch.autograd.grad(ls, xt)
     return out.detach(), ls.detach(), g.contiguous()

@@ -16,6 +16,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_${tag}
 cd $root
 python3 tools/prof_summary.py $out/prof_${tag}_learn $out/${tag}_learn_stats.md "bench.py (learn, ResNet-50, 512 images, 50 atoms, bf16 streams), rocprofv3 --kernel-trace --stats" > /dev/null
 python3 tools/prof_summary.py $out/prof_${tag}_inference $out/${tag}_inference_stats.md "bench.py --mode inference (DDrague iteration, ResNet-50, 512 images, 50 atoms, bf16 streams, fp32 z), rocprofv3 --kernel-trace --stats" > /dev/null
-python3 tools/step_breakdown.py $out/prof_${tag}_learn > $out/${tag}_learn_step_breakdown.txt
+python3 tools/step_breakdown.py $out/prof_${tag}_learn 23 > $out/${tag}_learn_step_breakdown.txt
+python3 tools/step_breakdown.py $out/prof_${tag}_learn 3 > $out/${tag}_learn_step_breakdown_cached_labels.txt
 python3 tools/pmc_traffic.py $out/pmc_${tag}_FETCH_SIZE $out/pmc_${tag}_WRITE_SIZE $out/${tag}_hbm_traffic.json > $out/${tag}_hbm_traffic.txt
 echo profiles done

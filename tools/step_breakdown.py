@@ -20,7 +20,11 @@ def short(n):
                      ('affine_act_bwd', 'affine_act_bwd'), ('batched_transpose', 'miopen_transpose'), ('fillBuffer', 'memset')):
         if key in n: return lab
     m = re.match(r'(?:void )?([\w:]+)', n); return (m.group(1) if m else n)[:44]
-a, b = idx[-3], idx[-2]
+# optional argv[2]: which synth launch opens the step, counted from the end (default 3: the step before the last complete
+# one).  bench.py's learn mode ends with `steps` extra steps of the cached-label variant, so the HEADLINE step of a run
+# with --steps 20 is e.g. argv[2] = 23.
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+a, b = idx[-back], idx[-back + 1]
 seg = rows[a:b]
 wall = int(rows[b]['Start_Timestamp']) - int(rows[a]['Start_Timestamp'])
 busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in seg)
