@@ -74,7 +74,7 @@ def _install_oracle_backend(O):
         def step(self, model, x, index, labels=None):
             if x.shape[0]:
                 with torch.no_grad():
-                    label = model(x).argmax(-1)
+                    label = model(x).argmax(-1) if labels is None else labels     # ADIL(cache_labels=True) hands them in
                 out, ls, gin = O._input_grad(model, O.synth(x, self.d, self.v[index]), label, self.loss, self.coeff,
                                              self.kappa, "sum")
                 gd, gvr = O.grad_dv(gin, self.d, self.v[index])
@@ -144,6 +144,16 @@ def _worker(rank, world, port, out_dir):
                    kappa=50.0, init_d=d0, init_v=v0raw, epoch_batches=explicit, val_batches=vexplicit,
                    dict_dir=os.path.join(out_dir, "dicts"), shuffle_seed=5)
         assert os.path.exists(atk.model_file)                      # rank 0 saved before the final barrier
+    # the same explicit scenario with the two classifier-work savers: cached pseudo-labels per OWNED image (local row
+    # numbers) and validation after the last epoch only — the file must come out identical
+    calls = {"n": 0}
+    hook = net.register_forward_hook(lambda *a: calls.__setitem__("n", calls["n"] + 1))
+    atk = ADIL(net, eps=EPS, steps=len(EXPLICIT), n_atoms=K, batch_size=BATCH, data_train=_Indexed(images),
+               data_val=_Indexed(val), model_name="dist_savers", step_size=0.01, is_distributed=True, loss="logits",
+               kappa=50.0, init_d=d0, init_v=v0raw, epoch_batches=EXPLICIT, val_batches=EXPLICIT_VAL,
+               dict_dir=os.path.join(out_dir, "dicts"), shuffle_seed=5, cache_labels=True, val_every=0)
+    hook.remove()
+    torch.save(calls["n"], os.path.join(out_dir, f"savers_forwards_rank{rank}.pt"))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -172,6 +182,10 @@ def test_product_distributed_learner_matches_single_process_global_batch(tmp_pat
         assert max(abs(a - b) for a, b in zip(ref["loss_all"], loss_all)) < 1e-4 * max(1.0, max(map(abs, ref["loss_all"])))
         assert list(fooling_rate_all) == list(ref["fooling_rate_all"])
         assert abs(float(val_fool) - ref["val_fool"]) < 1e-6
+    a = torch.load(tmp_path / "dicts" / "ImageNet_dist_explicit.bin")
+    b = torch.load(tmp_path / "dicts" / "ImageNet_dist_savers.bin")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] and float(a[4]) == float(b[4])
+    assert all(torch.load(tmp_path / f"savers_forwards_rank{r}.pt") > 0 for r in range(world))
 
 
 def test_global_epoch_batches_equal_steps_and_ownership():
