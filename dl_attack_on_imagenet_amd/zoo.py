@@ -9,7 +9,6 @@ are randomly initialised from a seed (synthetic throughput / plumbing runs).
 """
 from __future__ import annotations
 
-import math
 from collections import OrderedDict
 from typing import Optional
 
