@@ -1608,6 +1608,75 @@ __global__ __launch_bounds__(512) void gram_mfma_kernel(const float* __restrict_
     }
 }
 
+// =========================================================================================================== //
+// K7  out (P x K) = D M^T with M (K x K): D_dagger^T = D (DtD)^-1 (adil.py:525), fp32-grade on the bf16 matrix pipe.
+// M is staged once per workgroup (rows of M = output atoms, three bf16 planes, zero padded); the workgroup then walks
+// 32-pixel blocks of D: the block (one contiguous run of 32*K floats) goes to LDS as planes [pixel][atom] with coalesced
+// 16-byte loads (double buffered), wave t multiplies it with the rows of atom tile t of M and stores its 32 x 32 tile of
+// the result with the lanes along the atoms.  Round 1-2 had a scalar-FMA kernel here (76 us at K = 50, ~370 us at K = 100).
+// =========================================================================================================== //
+template <int AT>
+__global__ __launch_bounds__(AT * 64) void dict_rightmul_mfma_kernel(const float* __restrict__ d, const float* __restrict__ mat,
+                                                                     float* __restrict__ out, int P, int K, int Kp, int nblocks) {
+    using M = Mma<float>;
+    using DI = DImg<float>;
+    constexpr int NT = AT * 64, KA = AT * 32;
+    const int Ks = Kp + DPAD;
+    const int mplane = KA * Ks, dplane = 32 * Ks;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sm = reinterpret_cast<bf16_t*>(smem_raw);            // [3][KA][Ks]   M, row = output atom
+    bf16_t* sdb = sm + 3 * mplane;                               // [2][3][32][Ks]  D block, row = pixel
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    for (int i = tid; i < KA * Kp; i += NT) {                     // M -> planes (zero rows / columns beyond K)
+        const int r = i / Kp, k = i - r * Kp;
+        const float ok = (r < K && k < K) ? 1.0f : 0.0f;
+        DI::put(sm, r * Ks + k, mplane, mat[(size_t)(r < K ? r : K - 1) * K + (k < K ? k : K - 1)] * ok);
+    }
+    constexpr int DPT = (32 * KA + NT - 1) / NT;                  // elements of a 32 x Kp block per thread (Kp <= KA): 16
+    float dreg[DPT];
+    auto load_block = [&](int blk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) {
+            const int i = tid + e * NT;
+            const int r = i / Kp, k = i - r * Kp;
+            const int pix = blk * 32 + (r < 32 ? r : 31);
+            dreg[e] = d[(size_t)(pix < P ? pix : P - 1) * K + (k < K ? k : K - 1)];
+        }
+    };
+    auto write_block = [&](bf16_t* dst, int blk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) {
+            const int i = tid + e * NT;
+            const int r = i / Kp, k = i - r * Kp;
+            if (r < 32) DI::put(dst, r * Ks + k, dplane, dreg[e] * ((k < K && blk * 32 + r < P) ? 1.0f : 0.0f));
+        }
+    };
+    const int NG = Kp >> 4;
+    int blk = blockIdx.x;
+    if (blk < nblocks) { load_block(blk); write_block(sdb, blk); }
+    int buf = 0;
+    for (; blk < nblocks; blk += gridDim.x, buf ^= 1) {
+        const int nxt = blk + gridDim.x;
+        if (nxt < nblocks) load_block(nxt);
+        lds_barrier();                                          // M and block[buf] visible; block[buf^1] free
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const bf16_t* sblk = sdb + buf * 3 * dplane;
+        for (int g = 0; g < NG; ++g)
+            M::mma(acc, DI::load8(sblk + c * Ks + 16 * g + 8 * h, dplane), DI::load8(sm + (w * 32 + c) * Ks + 16 * g + 8 * h, mplane));
+        const int atom = w * 32 + c;
+        if (atom < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pix = blk * 32 + c_row(r, h);
+                if (pix < P) out[(size_t)pix * K + atom] = acc[r];
+            }
+        }
+        if (nxt < nblocks) write_block(sdb + (buf ^ 1) * 3 * dplane, nxt);
+    }
+}
+
 // codes transposed + converted to the MFMA element type: vpt[a][b] = vp[b][a]  (a < KA, b < Bp)
 template <typename E>
 __global__ __launch_bounds__(256) void transpose_codes_kernel(const float* __restrict__ vp, int Bp, int Kp, int KA,
@@ -1699,6 +1768,28 @@ extern "C" int adil_gram(const float* d, int P, int K, float* gram, void* ws, si
     if (at == 1) return launch_gram<1>(d, P, K, gram, (float*)ws, (hipStream_t)stream);
     if (at == 2) return launch_gram<2>(d, P, K, gram, (float*)ws, (hipStream_t)stream);
     return launch_gram<4>(d, P, K, gram, (float*)ws, (hipStream_t)stream);
+}
+
+// ---- K7 D M^T ----------------------------------------------------------------------------------------------- //
+template <int AT>
+static int launch_dict_rightmul(const float* d, const float* mat, int P, int K, float* out, hipStream_t st) {
+    const int Kp = round_up(K, 16), Ks = Kp + DPAD, nblocks = (P + 31) / 32;
+    const size_t lds = (3 * (size_t)AT * 32 * Ks + 2 * 3 * (size_t)32 * Ks) * sizeof(bf16_t);
+    int rc = set_lds((const void*)dict_rightmul_mfma_kernel<AT>, lds);
+    if (rc) return rc;
+    const int grid = nblocks < 4 * kNumCU ? nblocks : 4 * kNumCU;
+    hipLaunchKernelGGL((dict_rightmul_mfma_kernel<AT>), dim3(grid), dim3(AT * 64), lds, st, d, mat, out, P, K, Kp, nblocks);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_dict_rightmul(const float* d, const float* mat, int P, int K, float* out, void* stream) {
+    ADIL_ENTER();
+    if (!d || !mat || !out || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
+    const int at = grad_at(K);
+    if (at == 1) return launch_dict_rightmul<1>(d, mat, P, K, out, (hipStream_t)stream);
+    if (at == 2) return launch_dict_rightmul<2>(d, mat, P, K, out, (hipStream_t)stream);
+    return launch_dict_rightmul<4>(d, mat, P, K, out, (hipStream_t)stream);
 }
 
 extern "C" size_t adil_grad_workspace_bytes(int B, int P, int K) {

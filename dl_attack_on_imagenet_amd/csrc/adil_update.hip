@@ -308,28 +308,7 @@ __global__ __launch_bounds__(256) void atom_scale_kernel(float* __restrict__ d, 
     }
 }
 
-// ---- K7: D * M^T (the Gram matrix itself is an MFMA kernel: adil_gram in adil_contract.hip) ----------- //
-// out[p][k] = sum_j d[p][j] * mat[k][j]
-__global__ __launch_bounds__(256) void dict_rightmul_kernel(const float* __restrict__ d, const float* __restrict__ mat,
-                                                            int P, int K, int KT, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];     // mat [K][K+1] then rows [R][K]
-    float* smat = sm;
-    float* srow = sm + K * (K + 1);
-    const int R = 256 / KT;
-    for (int i = threadIdx.x; i < K * K; i += 256) smat[(i / K) * (K + 1) + (i % K)] = mat[i];
-    const int k = threadIdx.x % KT, r = threadIdx.x / KT;
-    for (int p0 = blockIdx.x * R; p0 < P; p0 += gridDim.x * R) {
-        __syncthreads();
-        const int nr = min(R, P - p0);
-        for (int i = threadIdx.x; i < nr * K; i += 256) srow[i] = d[(size_t)p0 * K + i];
-        __syncthreads();
-        if (r < nr && k < K) {
-            float acc = 0.0f;
-            for (int j = 0; j < K; ++j) acc += srow[r * K + j] * smat[k * (K + 1) + j];
-            out[(size_t)(p0 + r) * K + k] = acc;
-        }
-    }
-}
+// ---- K7: the Gram matrix and D * M^T are MFMA kernels in adil_contract.hip (adil_gram, adil_dict_rightmul) ---- //
 
 // ---- K12: per-image evaluation sums ----------------------------------------- //
 template <typename T>
@@ -511,22 +490,6 @@ extern "C" int adil_atom_scale(float* d, int P, int K, const float* norms, int s
     const size_t n = (size_t)P * K;
     hipLaunchKernelGGL(atom_scale_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, d, n, K, norms,
                        sphere);
-    ADIL_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int adil_dict_rightmul(const float* d, const float* mat, int P, int K, float* out, void* stream) {
-    ADIL_ENTER();
-    if (!d || !mat || !out || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
-    const int KT = pow2_at_least(K), R = 256 / KT;
-    const size_t lds = ((size_t)K * (K + 1) + (size_t)R * K) * sizeof(float);
-    int grid = (P + R - 1) / R;
-    if (grid > 1024) grid = 1024;
-    if (lds > 64 * 1024) {                                                   // K >= 127: above the default 64 KB cap
-        hipError_t e = hipFuncSetAttribute((const void*)dict_rightmul_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(dict_rightmul_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, d, mat, P, K, KT, out);
     ADIL_CHECK_LAUNCH();
     return 0;
 }

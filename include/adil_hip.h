@@ -162,7 +162,8 @@ int adil_gram(const float* d, int P, int K, float* gram, void* ws, size_t ws_byt
  * One workgroup, fp64 Gauss-Jordan in LDS; no host round trip. */
 int adil_spd_inverse(const float* a, int K, float* out, void* stream);
 
-/* out (P x K) = D M^T  with M (K x K):  D_dagger^T = D (DtD^-1)^T   (adil.py:525, stored P x K). */
+/* out (P x K) = D M^T  with M (K x K):  D_dagger^T = D (DtD^-1)^T   (adil.py:525, stored P x K); fp32-grade on the
+ * matrix pipe (split bf16 MFMAs). */
 int adil_dict_rightmul(const float* d, const float* mat, int P, int K, float* out, void* stream);
 
 /* Per-image evaluation sums (performance.py:249-266): sq_err[b] = sum_p (adv-x)^2, sq_norm[b] = sum_p x^2. */
