@@ -159,8 +159,9 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_product_distributed_learner_matches_single_process_global_batch(tmp_path):
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4])
+def test_product_distributed_learner_matches_single_process_global_batch(world, tmp_path):
+    port = _free_port()
     mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
     O, net, images, val, d0, v0raw = _problem()
     from dl_attack_on_imagenet_amd import dist as adist
@@ -172,7 +173,8 @@ def test_product_distributed_learner_matches_single_process_global_batch(tmp_pat
             vexplicit = [adist.global_epoch_batches(N_VAL, BATCH, world, 6, e) for e in range(STEPS)]
             sizes = [len(b) for b in explicit[0]]
             assert sorted(i for b in explicit[0] for i in b) == list(range(N_IMG))      # one epoch = every image once
-            assert sizes == [6, 6, 5]                              # 9 + 8 images in chunks of 3: equal step count, ragged tail
+            # 2 ranks: 9 + 8 images in chunks of 3; 4 ranks: 5 + 4 + 4 + 4 images in chunks of 1 — equal step count, ragged tail
+            assert sizes == ([6, 6, 5] if world == 2 else [4, 4, 4, 4, 1])
         # single-process reference at the same GLOBAL batches
         ref = O.learn_dictionary_a(net, images, d0, v0, explicit, EPS, 0.01, "logits", False, 50.0, val_images=val,
                                    val_batches=vexplicit)
