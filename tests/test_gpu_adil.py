@@ -401,21 +401,33 @@ def test_demo_cli_result_dumps(tmp_path, monkeypatch):
         assert a == b or (a != a and b != b)          # NaN when the synthetic labels leave nothing "correctly classified"
 
 
-def test_bench_starts_its_own_ranks(tmp_path):
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_starts_its_own_ranks(launcher, tmp_path):
     """`python bench.py --gpus 2` outside torchrun: the parent (which makes no GPU call) starts the two ranks itself and rank
-    0 prints ONE JSON line with n_gpus = 2.  This box has one GPU, so the rehearsal shares it (ADIL_SHARE_GPU=1) over gloo
-    (RCCL refuses two ranks on one device); rank plumbing, weak-scaling accounting, the per-step all-reduce of grad_d, the
-    max-over-ranks timing and the JSON contract are what is checked — not a scaling number."""
+    0 prints ONE JSON line with n_gpus = 2 — and the driver's own form, `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`, gives the same.  This box has one GPU,
+    so the rehearsal shares it (ADIL_SHARE_GPU=1) over gloo (RCCL refuses two ranks on one device); rank plumbing,
+    weak-scaling accounting, the per-step all-reduce of grad_d, the max-over-ranks timing and the JSON contract are what is
+    checked — not a scaling number."""
     import json
+    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ADIL_DIST_BACKEND="gloo", ADIL_SHARE_GPU="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--model", "resnet18", "--batch", "32", "--atoms", "10", "--cpu-baseline", "0"],
-                       env=env, capture_output=True, text=True, timeout=600)
+    bench = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--model", "resnet18",
+             "--batch", "32", "--atoms", "10", "--cpu-baseline", "0"]
+    if launcher == "self":
+        cmd = [sys.executable] + bench
+    else:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + bench
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -424,6 +436,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert out["config"]["global_batch"] == 64 and out["value"] > 0
     assert abs(out["value"] - 2 * 32 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     assert "cpu_baseline" not in out and out["roofline"]["bound"] == "hbm"
+    assert out["config"]["cached_labels_variant"]["images_per_sec"] > 0
 
 
 def test_transfer_evaluation_data_parallel(tmp_path):
