@@ -128,10 +128,27 @@ def main(args):
     return val_perf, test_perf
 
 
+class _CastLoader:
+    """A DataLoader whose image batches come out in `dtype`; everything else (`batch_size`, `dataset`, `len`) is the
+    wrapped loader's, which performance.py relies on (the classifier's batch bucket, the transfer evaluation's
+    `len(data.dataset)`, performance.py:130 / :207 here)."""
+
+    def __init__(self, loader, dtype):
+        self._loader, self._dtype = loader, dtype
+
+    def __iter__(self):
+        for x, y in self._loader:
+            yield x.to(self._dtype), y
+
+    def __len__(self):
+        return len(self._loader)
+
+    def __getattr__(self, name):
+        return getattr(self._loader, name)
+
+
 def _cast_loader(loader, dtype):
-    if dtype == torch.float32:
-        return loader
-    return [(x.to(dtype), y) for x, y in loader]
+    return loader if dtype == torch.float32 else _CastLoader(loader, dtype)
 
 
 if __name__ == '__main__':

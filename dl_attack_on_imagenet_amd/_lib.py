@@ -14,14 +14,17 @@ SIGNATURES = {
     "adil_abi_version": (c_int, []),
     "adil_max_atoms": (c_int, []),
     "adil_grad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "adil_pack_codes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "adil_grad_code_rows": (c_int, [c_int]),
+    "adil_grad_slab_offset": (c_size_t, [c_int, c_int, c_int]),
+    "adil_pack_codes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                c_void_p]),
     "adil_gather_images": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "adil_spd_inverse": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "adil_synth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "adil_synth_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                c_void_p]),
-    "adil_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                          c_size_t, c_void_p]),
+    "adil_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                          c_void_p, c_size_t, c_void_p, c_void_p]),
     "adil_adamw_clamp": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,
                                  c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "adil_zstep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
@@ -29,7 +32,7 @@ SIGNATURES = {
                            c_void_p, c_void_p]),
     "adil_adamw_l1ball": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
                                   c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
-                                  c_void_p]),
+                                  c_void_p, c_int, c_int, c_void_p]),
     "adil_l1ball_project": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     "adil_l2ball_project": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     "adil_ista_step": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p]),
@@ -57,7 +60,7 @@ SIGNATURES = {
                                    c_void_p]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 

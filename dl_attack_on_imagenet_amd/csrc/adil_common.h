@@ -78,7 +78,62 @@ __device__ __forceinline__ float adamw_elem(float p, float g, float& m, float& s
 }
 
 
+// --------------------------------------------------------------------------- //
+// Sum of one entry over the per-workgroup partial-sum slabs of a grad_v pass, in a FIXED order: slab s goes to
+// accumulator s % 32, the 32 accumulators meet in a pairwise tree.  Bitwise reproducible, and the same function serves
+// the stand-alone reduce kernel and the consumers that fold the reduction into their own launch (adamw_l1ball,
+// pack_codes), so both routes give identical bits.  p = address of the entry in slab 0, stride = floats per slab.
+// 32 independent loads are in flight per lane; the tail uses clamped addresses and 0/1 weights, never a branch around
+// a load (hipcc would serialise them, DESIGN finding 2).
+// --------------------------------------------------------------------------- //
+__device__ __forceinline__ float slab_sum(const float* __restrict__ p, int nslabs, size_t stride) {
+    float acc[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) acc[u] = 0.0f;
+    int s0 = 0;
+    for (; s0 + 32 <= nslabs; s0 += 32) {
+        float t[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) t[u] = p[(size_t)(s0 + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc[u] += t[u];
+    }
+    if (s0 < nslabs) {
+        float t[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int s = s0 + u;
+            t[u] = p[(size_t)(s < nslabs ? s : nslabs - 1) * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc[u] += ((s0 + u < nslabs) ? 1.0f : 0.0f) * t[u];
+    }
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {
+#pragma unroll
+        for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
+    }
+    return acc[0];
+}
+
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Compute units of the current device (grid sizing, per-workgroup scratch), asked once per device.  256 (MI355X) when
+// no device can be queried — the workspace-size entry points are also called on boxes without a GPU (build check).
+static inline int adil_num_cu() {
+    static int cached[32] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) { (void)hipGetLastError(); return 256; }
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            n = 256;
+        }
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
 
 // hipGetLastError is sticky per thread: drop whatever an earlier, unrelated HIP call (e.g. PyTorch's lazy device
 // probing) left behind so that ADIL_CHECK_LAUNCH reports only our own launch failures.

@@ -11,6 +11,9 @@
 // 8 consecutive indices 16g + 8h + j, j = 0..7, of row/column r — identical for both instruction shapes, so the
 // data movement is shared and only Mma<T>::mma differs (6 split MFMAs vs 1 bf16 MFMA per k-group).
 // C/D layout of a 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#include <mutex>
+#include <unordered_map>
+
 #include "adil_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1688,44 +1691,36 @@ __global__ __launch_bounds__(256) void transpose_codes_kernel(const float* __res
     if constexpr (sizeof(E) == 4) vpt[i] = v; else vpt[i] = f32_to_bf16(v);
 }
 
-// grad_vb[b][k] = sum over workgroup slabs.  64 consecutive (b, k) entries per block x 4 slab groups; every thread
-// keeps 8 independent loads in flight, the 4 groups meet in LDS in a fixed order (bitwise reproducible).
-__global__ __launch_bounds__(256) void grad_v_reduce_kernel(const float* __restrict__ slab, int nslabs, int Bp, int KA,
-                                                            int B, int K, float* __restrict__ grad_vb) {
-    __shared__ float part[4][64];
-    const int e = blockIdx.x * 64 + (threadIdx.x & 63);          // entry of the [Bp][KA] slab matrix (KA = row stride = K)
-    const int grp = threadIdx.x >> 6;
-    const size_t stride = (size_t)Bp * KA;
-    float acc[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] = 0.0f;
-    if (e < Bp * KA) {
-        int sidx = grp;
-        for (; sidx + 28 < nslabs; sidx += 32) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += slab[(size_t)(sidx + 4 * u) * stride + e];
-        }
-        for (; sidx < nslabs; sidx += 4) acc[0] += slab[(size_t)sidx * stride + e];
-    }
-    part[grp][threadIdx.x & 63] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-    __syncthreads();
-    if (grp == 0 && e < Bp * KA) {
-        const int b = e / KA, k = e - b * KA;
-        if (b < B && k < K)
-            grad_vb[(size_t)b * K + k] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-    }
+// grad_vb[b][k] = sum over the workgroup slabs (slab_sum: fixed order, 32 loads in flight per lane).  One entry per lane.
+// Used when the reduction cannot be left to the consumer (several row chunks share the slab area, or the caller asked
+// for a dense grad_vb); adil_adamw_l1ball / adil_pack_codes run the same sum inside their own launch otherwise.
+__global__ __launch_bounds__(64) void grad_v_reduce_kernel(const float* __restrict__ slab, int nslabs, int Bp, int KA,
+                                                           int B, int K, float* __restrict__ grad_vb) {
+    const int e = blockIdx.x * 64 + threadIdx.x;                 // entry of the [Bp][KA] slab matrix (KA = row stride = K)
+    if (e >= Bp * KA) return;
+    const int b = e / KA, k = e - b * KA;
+    if (b < B && k < K) grad_vb[(size_t)b * K + k] = slab_sum(slab + e, nslabs, (size_t)Bp * KA);
 }
 
 // =========================================================================================================== //
 // C ABI
 // =========================================================================================================== //
-static const int kNumCU = 256;                     // MI355X
+static inline int num_cu() { return adil_num_cu(); }     // 256 on MI355X (from hipDeviceAttributeMultiprocessorCount)
 
+// Dynamic LDS above 48 KB has to be allowed per kernel function; asked of the runtime once per (device, function, size),
+// not on every launch.
 static int set_lds(const void* fn, size_t bytes) {
-    if (bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return (int)e;
-    }
+    if (bytes <= 48 * 1024) return 0;
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> allowed[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return (int)hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = allowed[dev].find(fn);
+    if (it != allowed[dev].end() && it->second >= bytes) return 0;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    allowed[dev][fn] = bytes;
     return 0;
 }
 
@@ -1745,17 +1740,17 @@ static inline int atom_tiles(int K) { return (K + 31) / 32; }
 static inline int grad_at(int K) { const int a = atom_tiles(K); return a <= 2 ? a : 4; }       // instantiated: 1, 2, 4
 
 // ---- K7 Gram ------------------------------------------------------------------------------------------------ //
-extern "C" size_t adil_gram_workspace_bytes(int P, int K) { (void)P; return (size_t)kNumCU * K * K * sizeof(float); }
+extern "C" size_t adil_gram_workspace_bytes(int P, int K) { (void)P; return (size_t)num_cu() * K * K * sizeof(float); }
 
 template <int AT>
 static int launch_gram(const float* d, int P, int K, float* gram, float* ws, hipStream_t st) {
-    const int nt = (P + 31) / 32, tpw = (nt + kNumCU - 1) / kNumCU, nwg = (nt + tpw - 1) / tpw;
+    const int nt = (P + 31) / 32, tpw = (nt + num_cu() - 1) / num_cu(), nwg = (nt + tpw - 1) / tpw;
     const size_t lds = 2 * 3 * (size_t)AT * 32 * (32 + DPAD) * sizeof(bf16_t);
     int rc = set_lds((const void*)gram_mfma_kernel<AT>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((gram_mfma_kernel<AT>), dim3(nwg), dim3(512), lds, st, d, ws, P, K, nt, tpw);
     ADIL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((K * K + 63) / 64), dim3(256), 0, st, (const float*)ws, nwg, K, K, K, K, gram);
+    hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((K * K + 63) / 64), dim3(64), 0, st, (const float*)ws, nwg, K, K, K, K, gram);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
@@ -1777,7 +1772,7 @@ static int launch_dict_rightmul(const float* d, const float* mat, int P, int K, 
     const size_t lds = (3 * (size_t)AT * 32 * Ks + 2 * 3 * (size_t)32 * Ks) * sizeof(bf16_t);
     int rc = set_lds((const void*)dict_rightmul_mfma_kernel<AT>, lds);
     if (rc) return rc;
-    const int grid = nblocks < 4 * kNumCU ? nblocks : 4 * kNumCU;
+    const int grid = nblocks < 4 * num_cu() ? nblocks : 4 * num_cu();
     hipLaunchKernelGGL((dict_rightmul_mfma_kernel<AT>), dim3(grid), dim3(AT * 64), lds, st, d, mat, out, P, K, Kp, nblocks);
     ADIL_CHECK_LAUNCH();
     return 0;
@@ -1797,7 +1792,7 @@ extern "C" size_t adil_grad_workspace_bytes(int B, int P, int K) {
     const size_t KA = grad_at(K) * 32, Bp = round_up(B, 32);
     const size_t vpt = KA * Bp * sizeof(float);                       // transposed codes (grad_d)
     const size_t rows = Bp < 512 ? Bp : 512;
-    const size_t slab = (size_t)(2 * kNumCU + 2) * rows * KA * sizeof(float);   // grad_v partial sums per workgroup
+    const size_t slab = (size_t)(2 * num_cu() + 2) * rows * KA * sizeof(float);   // grad_v partial sums per workgroup
     return ((vpt + 255) / 256) * 256 + slab;
 }
 
@@ -1888,6 +1883,34 @@ extern "C" int adil_synth(const void* x, const float* d, const float* vp, void* 
 
 static inline int imin(int a, int b) { return a < b ? a : b; }
 
+// What the caller of adil_grad brings along / takes over (ABI 6).
+struct GradOpts {
+    const void* vpt_in;   // codes already transposed [KA][Bp] in the MFMA element type of the stream (adil_pack_codes), or null
+    int* nslabs_out;      // non-null: the caller reduces the grad_v slabs itself (adil_adamw_l1ball / adil_pack_codes) when
+                          // ONE row chunk covers the batch; receives the slab count, 0 = reduced here into grad_vb as usual
+};
+
+// vpt[a][b] = vp[b][a] in the element type E: supplied by the caller, or made here (one small launch)
+template <typename E>
+static int transposed_codes(const float* vp, const GradOpts& o, void* ws, int Bp, int Kp, int KA, hipStream_t st, const E** out) {
+    if (o.vpt_in != nullptr) { *out = reinterpret_cast<const E*>(o.vpt_in); return 0; }
+    E* vpt = reinterpret_cast<E*>(ws);
+    hipLaunchKernelGGL((transpose_codes_kernel<E>), dim3((KA * Bp + 255) / 256), dim3(256), 0, st, vp, Bp, Kp, KA, vpt);
+    ADIL_CHECK_LAUNCH();
+    *out = vpt;
+    return 0;
+}
+
+// after a row chunk's kernels wrote `nslabs` slabs: hand them to the caller (single chunk) or reduce them here
+static int finish_slabs(const float* slab, int nslabs, int rows, int rows_p, int K, float* grad_vb_rows, bool single_chunk,
+                        const GradOpts& o, hipStream_t st) {
+    if (o.nslabs_out != nullptr && single_chunk) { *o.nslabs_out = nslabs; return 0; }
+    hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows_p * K + 63) / 64), dim3(64), 0, st, slab, nslabs, rows_p, K, rows, K,
+                       grad_vb_rows);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T, int PXT, int AT, bool FAST>
 static int launch_grad_d_range(const T* g, const typename Mma<T>::Elem* vpt, int vstride, float* grad_d, int B, int Bp,
                                int P, int K, int acc_d, int tile_begin, int tile_end, hipStream_t st) {
@@ -1901,18 +1924,18 @@ static int launch_grad_d_range(const T* g, const typename Mma<T>::Elem* vpt, int
 
 template <typename T, int PXT, int AT>
 static int launch_grad_d(const T* g, const float* vp, float* grad_d, int B, int P, int K, int accumulate_d, void* ws,
-                         hipStream_t st) {
+                         const GradOpts& o, hipStream_t st) {
     using E = typename Mma<T>::Elem;
     constexpr int KA = AT * 32;
     constexpr int TW = PXT * 32;
     const int Kp = round_up(K, 16), Bp = round_up(B, 32);
-    E* vpt = reinterpret_cast<E*>(ws);
-    hipLaunchKernelGGL((transpose_codes_kernel<E>), dim3((KA * Bp + 255) / 256), dim3(256), 0, st, vp, Bp, Kp, KA, vpt);
-    ADIL_CHECK_LAUNCH();
+    const E* vpt;
+    int rc = transposed_codes<E>(vp, o, ws, Bp, Kp, KA, st, &vpt);
+    if (rc) return rc;
     const int ntiles = (P + TW - 1) / TW;
     const bool vec = (P % 4 == 0) && ((uintptr_t)g % 16 == 0);
     const int nfast = vec ? P / TW : 0;
-    int rc = launch_grad_d_range<T, PXT, AT, true>(g, vpt, Bp, grad_d, B, Bp, P, K, accumulate_d, 0, nfast, st);
+    rc = launch_grad_d_range<T, PXT, AT, true>(g, vpt, Bp, grad_d, B, Bp, P, K, accumulate_d, 0, nfast, st);
     if (rc) return rc;
     return launch_grad_d_range<T, PXT, AT, false>(g, vpt, Bp, grad_d, B, Bp, P, K, accumulate_d, nfast, ntiles, st);
 }
@@ -1955,20 +1978,21 @@ static int launch_grad_v_range(const T* g, const float* d, float* slab, int rows
 }
 
 template <typename T, int AT>
-static int launch_grad_v(const T* g, const float* d, float* grad_vb, int B, int P, int K, float* slab, hipStream_t st) {
+static int launch_grad_v(const T* g, const float* d, float* grad_vb, int B, int P, int K, float* slab, const GradOpts& o,
+                         hipStream_t st) {
     constexpr int KA = AT * 32;
     const int Bp = round_up(B, 32);
     const int ntiles = (P + GV_TW - 1) / GV_TW;
     const bool vec = (P % 8 == 0) && ((uintptr_t)g % 16 == 0);
     const int nfast = vec ? P / GV_TW : 0, nslow = ntiles - nfast;
-    const int tpw_fast = nfast > 0 ? (nfast + kNumCU - 1) / kNumCU : 1;
+    const int tpw_fast = nfast > 0 ? (nfast + num_cu() - 1) / num_cu() : 1;
     const int nwg_fast = nfast > 0 ? (nfast + tpw_fast - 1) / tpw_fast : 0;
-    const int tpw_slow = nslow > 0 ? (nslow + kNumCU - 1) / kNumCU : 1;
+    const int tpw_slow = nslow > 0 ? (nslow + num_cu() - 1) / num_cu() : 1;
     const int nwg_slow = nslow > 0 ? (nslow + tpw_slow - 1) / tpw_slow : 0;
     if constexpr (sizeof(T) == 4) {
         if (vec && P % 32 == 0) {             // fp32 streams: planes split once; 512 rows per launch (K > 64: 256, the D planes double)
             constexpr int kRows = AT <= 2 ? 512 : 256;
-            const int nt = P / 32, tpw = (nt + kNumCU - 1) / kNumCU, nwg = (nt + tpw - 1) / tpw;
+            const int nt = P / 32, tpw = (nt + num_cu() - 1) / num_cu(), nwg = (nt + tpw - 1) / tpw;
             for (int r0 = 0; r0 < Bp; r0 += kRows) {
                 const int rows_p = imin(Bp - r0, kRows), rows = imin(B - r0, rows_p);
                 const float* gc = (const float*)g + (size_t)r0 * P;
@@ -1982,9 +2006,8 @@ static int launch_grad_v(const T* g, const float* d, float* grad_vb, int B, int 
                     else rc = launch_grad_v_f32_nw<AT, 4>(gc, d, slab, rows, rows_p, P, K, nt, tpw, nwg, st);
                 }
                 if (rc) return rc;
-                hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows_p * K + 63) / 64), dim3(256), 0, st, (const float*)slab,
-                                   nwg, rows_p, K, rows, K, grad_vb + (size_t)r0 * K);
-                ADIL_CHECK_LAUNCH();
+                rc = finish_slabs(slab, nwg, rows, rows_p, K, grad_vb + (size_t)r0 * K, Bp <= kRows, o, st);
+                if (rc) return rc;
             }
             return 0;
         }
@@ -1998,9 +2021,8 @@ static int launch_grad_v(const T* g, const float* d, float* grad_vb, int B, int 
         rc = launch_grad_v_range<T, AT, false>(gc, d, slab + (size_t)nwg_fast * rows_p * K, rows, rows_p, P, K, nfast,
                                                ntiles, nwg_slow, tpw_slow, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows_p * K + 63) / 64), dim3(256), 0, st, (const float*)slab,
-                           nwg_fast + nwg_slow, rows_p, K, rows, K, grad_vb + (size_t)r0 * K);   // slab rows are K wide
-        ADIL_CHECK_LAUNCH();
+        rc = finish_slabs(slab, nwg_fast + nwg_slow, rows, rows_p, K, grad_vb + (size_t)r0 * K, Bp <= chunk, o, st);   // slab rows are K wide
+        if (rc) return rc;
     }
     return 0;
 }
@@ -2059,26 +2081,28 @@ static int launch_grad_fused_range(const T* g, const float* d, const typename Mm
 
 template <typename T, int AT>
 static int launch_grad_fused(const T* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P,
-                             int K, int accumulate_d, void* ws, float* slab, hipStream_t st) {
+                             int K, int accumulate_d, void* ws, float* slab, const GradOpts& o, hipStream_t st) {
     using E = typename Mma<T>::Elem;
     constexpr int KA = AT * 32;
     const int Kp = round_up(K, 16), Bp = round_up(B, 32);
-    E* vpt = reinterpret_cast<E*>(ws);
-    hipLaunchKernelGGL((transpose_codes_kernel<E>), dim3((KA * Bp + 255) / 256), dim3(256), 0, st, vp, Bp, Kp, KA, vpt);
-    ADIL_CHECK_LAUNCH();
+    const E* vpt;
+    {
+        int rc = transposed_codes<E>(vp, o, ws, Bp, Kp, KA, st, &vpt);
+        if (rc) return rc;
+    }
     const int ntiles = (P + GV_TW - 1) / GV_TW;
     const bool vec = (P % 8 == 0) && ((uintptr_t)g % 16 == 0);
     const int nfast = vec ? P / GV_TW : 0, nslow = ntiles - nfast;
-    const int tpw_fast = nfast > 0 ? (nfast + kNumCU - 1) / kNumCU : 1;
+    const int tpw_fast = nfast > 0 ? (nfast + num_cu() - 1) / num_cu() : 1;
     const int nwg_fast = nfast > 0 ? (nfast + tpw_fast - 1) / tpw_fast : 0;
-    const int tpw_slow = nslow > 0 ? (nslow + kNumCU - 1) / kNumCU : 1;
+    const int tpw_slow = nslow > 0 ? (nslow + num_cu() - 1) / num_cu() : 1;
     const int nwg_slow = nslow > 0 ? (nslow + tpw_slow - 1) / tpw_slow : 0;
     const int chunk = FusedCfg<T, AT>::kMaxRows;
     if constexpr (sizeof(T) == 4 && AT <= 2) {
         // fp32 streams, aligned rows, whole 32-pixel tiles: every operand split once (grad_fused_f32_kernel)
         if (vec && P % 32 == 0) {
             constexpr int NW = 8, TW = 32;
-            const int nt = P / TW, tpw = (nt + kNumCU - 1) / kNumCU, nwg = (nt + tpw - 1) / tpw;
+            const int nt = P / TW, tpw = (nt + num_cu() - 1) / num_cu(), nwg = (nt + tpw - 1) / tpw;
             const size_t lds = (2 * 3 * (size_t)KA * (TW + DPAD) + 3 * (size_t)NW * 32 * (TW + DPAD)) * sizeof(bf16_t) +
                                (size_t)NW * 16 * 64 * sizeof(float);
             int rc = set_lds((const void*)grad_fused_f32_kernel<AT, NW, false>, lds);
@@ -2095,9 +2119,8 @@ static int launch_grad_fused(const T* g, const float* d, const float* vp, float*
                     hipLaunchKernelGGL((grad_fused_f32_kernel<AT, NW, false>), dim3(nwg), dim3(NW * 64), lds, st, gc, d,
                                        (const float*)vpt + r0, Bp, grad_d, slab, rows, rows_p, P, K, nt, tpw);
                 ADIL_CHECK_LAUNCH();
-                hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows_p * K + 63) / 64), dim3(256), 0, st, (const float*)slab,
-                                   nwg, rows_p, K, rows, K, grad_vb + (size_t)r0 * K);
-                ADIL_CHECK_LAUNCH();
+                rc = finish_slabs(slab, nwg, rows, rows_p, K, grad_vb + (size_t)r0 * K, Bp <= NW * 32, o, st);
+                if (rc) return rc;
             }
             return 0;
         }
@@ -2112,9 +2135,8 @@ static int launch_grad_fused(const T* g, const float* d, const float* vp, float*
         rc = launch_grad_fused_range<T, AT, false>(gc, d, vpt + r0, Bp, grad_d, slab + (size_t)nwg_fast * rows_p * K, rows,
                                                    rows_p, P, K, acc_d, nfast, ntiles, nwg_slow, tpw_slow, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(grad_v_reduce_kernel, dim3((rows_p * K + 63) / 64), dim3(256), 0, st, (const float*)slab,
-                           nwg_fast + nwg_slow, rows_p, K, rows, K, grad_vb + (size_t)r0 * K);   // slab rows are K wide
-        ADIL_CHECK_LAUNCH();
+        rc = finish_slabs(slab, nwg_fast + nwg_slow, rows, rows_p, K, grad_vb + (size_t)r0 * K, Bp <= chunk, o, st);   // slab rows are K wide
+        if (rc) return rc;
     }
     return 0;
 }
@@ -2143,18 +2165,20 @@ static int launch_grad_d_lds_nw(const T* g, const typename Mma<T>::Elem* vpt, in
 
 template <typename T, int AT>
 static int launch_grad_d_lds(const T* g, const float* vp, float* grad_d, int B, int P, int K, int accumulate_d, void* ws,
-                             hipStream_t st) {
+                             const GradOpts& o, hipStream_t st) {
     using E = typename Mma<T>::Elem;
     constexpr int KA = AT * 32;
     const int Kp = round_up(K, 16), Bp = round_up(B, 32);
-    E* vpt = reinterpret_cast<E*>(ws);
-    hipLaunchKernelGGL((transpose_codes_kernel<E>), dim3((KA * Bp + 255) / 256), dim3(256), 0, st, vp, Bp, Kp, KA, vpt);
-    ADIL_CHECK_LAUNCH();
+    const E* vpt;
+    {
+        int rc = transposed_codes<E>(vp, o, ws, Bp, Kp, KA, st, &vpt);
+        if (rc) return rc;
+    }
     const int ntiles = (P + GV_TW - 1) / GV_TW;
     const bool vec = (P % 8 == 0) && ((uintptr_t)g % 16 == 0);
     const int nfast = vec ? P / GV_TW : 0, nslow = ntiles - nfast;
-    const int tpw_fast = nfast > 0 ? (nfast + kNumCU - 1) / kNumCU : 1, nwg_fast = nfast > 0 ? (nfast + tpw_fast - 1) / tpw_fast : 0;
-    const int tpw_slow = nslow > 0 ? (nslow + kNumCU - 1) / kNumCU : 1, nwg_slow = nslow > 0 ? (nslow + tpw_slow - 1) / tpw_slow : 0;
+    const int tpw_fast = nfast > 0 ? (nfast + num_cu() - 1) / num_cu() : 1, nwg_fast = nfast > 0 ? (nfast + tpw_fast - 1) / tpw_fast : 0;
+    const int tpw_slow = nslow > 0 ? (nslow + num_cu() - 1) / num_cu() : 1, nwg_slow = nslow > 0 ? (nslow + tpw_slow - 1) / tpw_slow : 0;
     for (int r0 = 0; r0 < Bp; r0 += 512) {
         const int rows_p = imin(Bp - r0, 512), rows = imin(B - r0, rows_p);
         const T* gc = g + (size_t)r0 * P;
@@ -2177,15 +2201,15 @@ static int launch_grad_d_lds(const T* g, const float* vp, float* grad_d, int B, 
 // ---- grad_d alone, fp32 streams, K > 64: the grad_d half of grad_fused_f32_kernel (pre-split operands), 256 rows per launch -- //
 template <int AT>
 static int launch_grad_d_f32_lds(const float* g, const float* vp, float* grad_d, int B, int P, int K, int accumulate_d, void* ws,
-                                 hipStream_t st) {
+                                 const GradOpts& o, hipStream_t st) {
     constexpr int KA = AT * 32, NW = 8, TW = 32;
     const int Kp = round_up(K, 16), Bp = round_up(B, 32);
-    float* vpt = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL((transpose_codes_kernel<float>), dim3((KA * Bp + 255) / 256), dim3(256), 0, st, vp, Bp, Kp, KA, vpt);
-    ADIL_CHECK_LAUNCH();
-    const int nt = P / TW, tpw = (nt + kNumCU - 1) / kNumCU, nwg = (nt + tpw - 1) / tpw;
+    const float* vpt;
+    int rc = transposed_codes<float>(vp, o, ws, Bp, Kp, KA, st, &vpt);
+    if (rc) return rc;
+    const int nt = P / TW, tpw = (nt + num_cu() - 1) / num_cu(), nwg = (nt + tpw - 1) / tpw;
     const size_t lds = 3 * (size_t)NW * 32 * (TW + DPAD) * sizeof(bf16_t) + (size_t)NW * 16 * 64 * sizeof(float);
-    int rc = set_lds((const void*)grad_fused_f32_kernel<AT, NW, false, false>, lds);
+    rc = set_lds((const void*)grad_fused_f32_kernel<AT, NW, false, false>, lds);
     if (rc) return rc;
     rc = set_lds((const void*)grad_fused_f32_kernel<AT, NW, true, false>, lds);
     if (rc) return rc;
@@ -2205,7 +2229,7 @@ static int launch_grad_d_f32_lds(const float* g, const float* vp, float* grad_d,
 
 template <typename T, int PXT, int AT>
 static int launch_grad_cfg(const T* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P,
-                           int K, int accumulate_d, void* ws, hipStream_t st) {
+                           int K, int accumulate_d, void* ws, const GradOpts& o, hipStream_t st) {
     constexpr int KA = AT * 32;
     const int Bp = round_up(B, 32);
     float* slab = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + (((size_t)KA * Bp * sizeof(float) + 255) / 256) * 256);
@@ -2223,44 +2247,55 @@ static int launch_grad_cfg(const T* g, const float* d, const float* vp, float* g
         // kernels win once grad_d goes through LDS in 512-row launches (launch_grad_d_lds)
         const bool fused = (AT == 4 && sizeof(T) == 2) ? Bp <= kRows : Bp <= 4 * kRows;
         if (grad_d != nullptr && grad_vb != nullptr && fused)
-            return launch_grad_fused<T, AT>(g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, slab, st);
+            return launch_grad_fused<T, AT>(g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, slab, o, st);
     }
     if constexpr (AT == 4 && sizeof(T) == 2) {
-        if (grad_d != nullptr) rc = launch_grad_d_lds<T, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, st);
+        if (grad_d != nullptr) rc = launch_grad_d_lds<T, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, o, st);
     } else if constexpr (AT == 4 && sizeof(T) == 4) {
         if (grad_d != nullptr) {
             if (P % 32 == 0 && (uintptr_t)g % 16 == 0)
-                rc = launch_grad_d_f32_lds<AT>((const float*)g, vp, grad_d, B, P, K, accumulate_d, ws, st);
+                rc = launch_grad_d_f32_lds<AT>((const float*)g, vp, grad_d, B, P, K, accumulate_d, ws, o, st);
             else
-                rc = launch_grad_d<T, PXT, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, st);
+                rc = launch_grad_d<T, PXT, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, o, st);
         }
     } else {
-        if (grad_d != nullptr) rc = launch_grad_d<T, PXT, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, st);
+        if (grad_d != nullptr) rc = launch_grad_d<T, PXT, AT>(g, vp, grad_d, B, P, K, accumulate_d, ws, o, st);
     }
     if (rc) return rc;
-    if (grad_vb != nullptr) rc = launch_grad_v<T, AT>(g, d, grad_vb, B, P, K, slab, st);
+    if (grad_vb != nullptr) rc = launch_grad_v<T, AT>(g, d, grad_vb, B, P, K, slab, o, st);
     return rc;
 }
 
 template <typename T>
 static int launch_grad(const void* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P,
-                       int K, int accumulate_d, void* ws, hipStream_t st) {
+                       int K, int accumulate_d, void* ws, const GradOpts& o, hipStream_t st) {
     const int at = grad_at(K);
-    if (at == 1) return launch_grad_cfg<T, 4, 1>((const T*)g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, st);
-    if (at == 2) return launch_grad_cfg<T, 2, 2>((const T*)g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, st);
-    return launch_grad_cfg<T, 2, 4>((const T*)g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, st);
+    if (at == 1) return launch_grad_cfg<T, 4, 1>((const T*)g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, o, st);
+    if (at == 2) return launch_grad_cfg<T, 2, 2>((const T*)g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, o, st);
+    return launch_grad_cfg<T, 2, 4>((const T*)g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, o, st);
 }
 
-extern "C" int adil_grad(const void* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P,
-                         int K, int dtype, int accumulate_d, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int adil_grad_code_rows(int K) { return (K > 0 && K <= ADIL_MAX_ATOMS) ? grad_at(K) * 32 : 0; }
+
+extern "C" size_t adil_grad_slab_offset(int B, int P, int K) {
+    (void)P;
+    return (((size_t)grad_at(K) * 32 * round_up(B, 32) * sizeof(float) + 255) / 256) * 256;
+}
+
+extern "C" int adil_grad(const void* g, const float* d, const float* vp, const void* vpt, float* grad_d, float* grad_vb,
+                         int B, int P, int K, int dtype, int accumulate_d, void* ws, size_t ws_bytes, int* nslabs_out,
+                         void* stream) {
     ADIL_ENTER();
+    if (nslabs_out != nullptr) *nslabs_out = 0;
     if (!g || B <= 0 || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
     if (grad_d == nullptr && grad_vb == nullptr) return ADIL_EINVAL;
     if (grad_d != nullptr && !vp) return ADIL_EINVAL;
     if (grad_vb != nullptr && !d) return ADIL_EINVAL;
+    if (vpt != nullptr && ((uintptr_t)vpt & 15)) return ADIL_EINVAL;
     if (!ws || ws_bytes < adil_grad_workspace_bytes(B, P, K)) return ADIL_EWORKSPACE;
-    if (dtype == ADIL_F32) return launch_grad<float>(g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, (hipStream_t)stream);
-    if (dtype == ADIL_BF16) return launch_grad<bf16_t>(g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, (hipStream_t)stream);
+    const GradOpts o{vpt, grad_vb != nullptr ? nslabs_out : nullptr};
+    if (dtype == ADIL_F32) return launch_grad<float>(g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, o, (hipStream_t)stream);
+    if (dtype == ADIL_BF16) return launch_grad<bf16_t>(g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, o, (hipStream_t)stream);
     return ADIL_EINVAL;
 }
 

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void adamw_l1ball_kernel(float* __restrict__ v
                                                            float radius, float* max_abs_delta, int do_adam,
                                                            int reset_pos, const float* skip_if_below,
                                                            float skip_threshold, float* clear,
-                                                           const float* __restrict__ dyn) {
+                                                           const float* __restrict__ dyn,
+                                                           const float* __restrict__ slabs, int nslabs, int slab_rows) {
     if (dyn != nullptr) { h.step_size = dyn[0]; h.bc2_sqrt = dyn[1]; }   // step-dependent scalars from device memory (graphs)
     // device-side stop test of the solver loop (adil.py:614), see zstep_mfma_kernel
     if (skip_if_below != nullptr && *skip_if_below < skip_threshold) {
@@ -140,7 +141,12 @@ __global__ __launch_bounds__(256) void adamw_l1ball_kernel(float* __restrict__ v
             x_old[e] = val;
             if (do_adam) {
                 float mm = m[i], ss = s[i];
-                const float g = (slot >= 0) ? grad_vb[(size_t)slot * K + k] : 0.0f;
+                // the batch gradient row: dense, or still in the producer's per-workgroup slabs (summed here in the fixed
+                // order of slab_sum: the reduction launch between adil_grad and this kernel is gone)
+                float g = 0.0f;
+                if (slot >= 0)
+                    g = (nslabs > 0) ? slab_sum(slabs + (size_t)slot * K + k, nslabs, (size_t)slab_rows * K)
+                                     : grad_vb[(size_t)slot * K + k];
                 val = adamw_elem(val, g, mm, ss, h);
                 m[i] = mm; s[i] = ss;
             }
@@ -199,19 +205,33 @@ __global__ __launch_bounds__(256) void ista_kernel(float* __restrict__ v, const 
 }
 
 // ---- gather + pad the batch's code rows ------------------------------------ //
+// vp[b][k] = source row b (k < K, b < B; else 0) with the source either v[index[b]] or the SUM over the per-workgroup
+// slabs of a grad_v pass (slab_sum: the reduce launch behind adil_grad folded into this one).  Optionally the same
+// values transposed, vpt[a][b] for a < A (rows >= K zero), in fp32 or bf16: the B operand of grad_d, which adil_grad
+// otherwise produces with a launch of its own.
+template <typename E>
 __global__ __launch_bounds__(256) void pack_codes_kernel(const float* __restrict__ v, const int64_t* __restrict__ index,
                                                          int B, int K, int Kp, int Bp, float* __restrict__ vp,
-                                                         int32_t* __restrict__ pos) {
+                                                         int32_t* __restrict__ pos, E* __restrict__ vpt, int A,
+                                                         const float* __restrict__ slabs, int nslabs, int slab_rows) {
+    const int W = (vpt != nullptr) ? A : Kp;                       // A >= Kp always
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Bp * Kp) return;
-    const int b = i / Kp, k = i - b * Kp;
+    if (i >= Bp * W) return;
+    const int b = i / W, k = i - b * W;
     float val = 0.0f;
     if (b < B && k < K) {
-        const int64_t row = (index != nullptr) ? index[b] : (int64_t)b;
-        val = v[row * K + k];
-        if (k == 0 && pos != nullptr) pos[row] = b;     // batch slot of code row `row` (consumed + reset by K5)
+        if (nslabs > 0) {
+            val = slab_sum(slabs + (size_t)b * K + k, nslabs, (size_t)slab_rows * K);
+        } else {
+            const int64_t row = (index != nullptr) ? index[b] : (int64_t)b;
+            val = v[row * K + k];
+            if (k == 0 && pos != nullptr) pos[row] = b;     // batch slot of code row `row` (consumed + reset by K5)
+        }
     }
-    vp[i] = val;
+    if (k < Kp) vp[(size_t)b * Kp + k] = val;
+    if (vpt != nullptr) {
+        if constexpr (sizeof(E) == 4) vpt[(size_t)k * Bp + b] = val; else vpt[(size_t)k * Bp + b] = f32_to_bf16(val);
+    }
 }
 
 // ---- batched image gather (the data step in front of the path) -------------- //
@@ -343,17 +363,27 @@ static inline int stream_grid(size_t work_items, int per_block) {
     return (int)b;
 }
 
-extern "C" int adil_abi_version(void) { return 5; }
+extern "C" int adil_abi_version(void) { return 6; }
 extern "C" int adil_max_atoms(void) { return ADIL_MAX_ATOMS; }
 
-extern "C" int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, int32_t* pos,
-                               void* stream) {
+extern "C" int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, int32_t* pos, void* vpt,
+                               int vpt_dtype, const float* slabs, int nslabs, int slab_rows, void* stream) {
     ADIL_ENTER();
-    if (!v || !vp || B <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
-    const int Kp = round_up(K, 16), Bp = round_up(B, 32);
-    const int total = Bp * Kp;
-    hipLaunchKernelGGL(pack_codes_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, index, B, K,
-                       Kp, Bp, vp, pos);
+    if (!vp || B <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
+    if (nslabs > 0 ? (!slabs || slab_rows < B || pos != nullptr) : !v) return ADIL_EINVAL;
+    if (nslabs < 0 || (vpt != nullptr && ((uintptr_t)vpt & 15))) return ADIL_EINVAL;
+    const int Kp = round_up(K, 16), Bp = round_up(B, 32), A = adil_grad_code_rows(K);
+    const int total = Bp * (vpt != nullptr ? A : Kp);
+    const dim3 grid((total + 255) / 256), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (vpt == nullptr || vpt_dtype == ADIL_F32)
+        hipLaunchKernelGGL(pack_codes_kernel<float>, grid, block, 0, st, v, index, B, K, Kp, Bp, vp, pos, (float*)vpt, A, slabs,
+                           nslabs, slab_rows);
+    else if (vpt_dtype == ADIL_BF16)
+        hipLaunchKernelGGL(pack_codes_kernel<bf16_t>, grid, block, 0, st, v, index, B, K, Kp, Bp, vp, pos, (bf16_t*)vpt, A, slabs,
+                           nslabs, slab_rows);
+    else
+        return ADIL_EINVAL;
     ADIL_CHECK_LAUNCH();
     return 0;
 }
@@ -416,14 +446,15 @@ extern "C" int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, 
 static int launch_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, float* m, float* s, int N, int K,
                                AdamWHyper h, float radius, float* max_abs_delta, int do_adam, int reset_pos,
                                hipStream_t st, const float* skip_if_below = nullptr, float skip_threshold = 0.0f,
-                               float* clear = nullptr, const float* dyn = nullptr) {
+                               float* clear = nullptr, const float* dyn = nullptr, const float* slabs = nullptr,
+                               int nslabs = 0, int slab_rows = 0) {
     const dim3 grid((N + 3) / 4), block(256);
     if (K <= 64)
         hipLaunchKernelGGL(adamw_l1ball_kernel<1>, grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
-                           max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear, dyn);
+                           max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear, dyn, slabs, nslabs, slab_rows);
     else
         hipLaunchKernelGGL(adamw_l1ball_kernel<2>, grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
-                           max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear, dyn);
+                           max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear, dyn, slabs, nslabs, slab_rows);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
@@ -431,13 +462,16 @@ static int launch_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, flo
 extern "C" int adil_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, int reset_pos, float* m, float* s, int N,
                                  int K, float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt,
                                  float radius, float* max_abs_delta, const float* skip_if_below, float skip_threshold,
-                                 float* clear, const float* dyn_scalars, void* stream) {
+                                 float* clear, const float* dyn_scalars, const float* slabs, int nslabs, int slab_rows,
+                                 void* stream) {
     ADIL_ENTER();
     if (!v || !m || !s || N <= 0 || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
-    if (!grad_vb && !pos) return ADIL_EINVAL;      // without a slot table every row reads its own gradient row
+    if (nslabs < 0 || (nslabs > 0 && (!slabs || slab_rows <= 0))) return ADIL_EINVAL;
+    if (!grad_vb && !pos && nslabs == 0) return ADIL_EINVAL;      // without a slot table every row reads its own gradient row
+    if (!pos && nslabs > 0 && slab_rows < N) return ADIL_EINVAL;
     AdamWHyper h{decay, b1, b2, eps, step_size, bc2_sqrt};
     return launch_adamw_l1ball(v, grad_vb, pos, m, s, N, K, h, radius, max_abs_delta, 1, reset_pos, (hipStream_t)stream,
-                               skip_if_below, skip_threshold, clear, dyn_scalars);
+                               skip_if_below, skip_threshold, clear, dyn_scalars, slabs, nslabs, slab_rows);
 }
 
 extern "C" int adil_l1ball_project(float* x, int N, int K, float radius, void* stream) {

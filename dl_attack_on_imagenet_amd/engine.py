@@ -181,13 +181,18 @@ class DictionaryLearner:
         b = x.shape[0]
         if b == 0:
             return self._empty_batch(x, want_d)
-        # the gather of the batch's code rows also records their batch slots in `pos` (consumed + reset by update_v)
-        vp = ops.pack_codes(self.v, index, b, pos=self.pos if want_v else None)
+        # the gather of the batch's code rows also records their batch slots in `pos` (consumed + reset by update_v) and,
+        # for a D-step, writes the transposed copy in the stream dtype that the grad_d contraction reads
+        vp = ops.pack_codes(self.v, index, b, pos=self.pos if want_v else None, transposed=x.dtype if want_d else None)
+        vpt = None
+        if want_d:
+            vp, vpt = vp
         xt = ops.synth(_flat_images(x), self.d, vp, b, fp8_absmax=self.fp8_absmax)      # K1
         out, ls, g = input_gradient(model, xt, labels, self.loss, self.coeff, self.kappa, "sum")
         fooled = (out.argmax(dim=-1) != labels).sum()                                    # adil.py:177
-        gd, gvb = ops.grad(g, self.d, vp, b, want_d=want_d, want_v=want_v,                # K2 + K3, one pass over g
-                           grad_d=self.grad_d if want_d else None)
+        # K2 + K3, one pass over g; grad_v stays in the kernel's per-workgroup partial sums, which update_v sums itself
+        gd, gvb = ops.grad(g, self.d, vp, b, want_d=want_d, want_v=want_v, grad_d=self.grad_d if want_d else None,
+                           vpt=vpt, defer_v=True)
         self._pending = None
         if want_d and self.reducer is not None:
             # the ONE collective per step, started here and waited for in update_d: the update of the code rows, which
@@ -325,7 +330,7 @@ def solve_codes_adamw(model, images: Tensor, d: Tensor, eps: float, loss: str = 
         vp = ops.pack_codes(v, None, b)
         xt = ops.synth(images, d, vp, b)
         _, _, g = input_gradient(model, xt, labels, loss, coeff, kappa, ce_reduction)
-        _, gvb = ops.grad(g, d, None, b, want_d=False, want_v=True)
+        _, gvb = ops.grad(g, d, None, b, want_d=False, want_v=True, defer_v=True)
         ops.adamw_l1ball_(v, gvb, None, m, s, sched.next(), eps, stop=stop)                # adil.py:609-610
         if (it + 1) % STOP_POLL == 0 and stop.converged():     # launches after the converged one are no-ops
             break
@@ -388,8 +393,9 @@ class DDragueSolver:
         self.stop.reset()
         return self
 
-    def codes(self) -> Tensor:
-        _, vcode = ops.grad(self.z, self.dpt, None, self.b, want_d=False, want_v=True)  # v = z D_dagger^T (K6)
+    def codes(self, defer: bool = False):
+        """v = z D_dagger^T (K6, adil.py:542).  defer: for pack_codes only — possibly still as partial sums (ops.SlabGrad)."""
+        _, vcode = ops.grad(self.z, self.dpt, None, self.b, want_d=False, want_v=True, defer_v=defer)
         return vcode
 
     def iterate(self, dyn: Optional[Tensor] = None) -> None:
@@ -397,10 +403,10 @@ class DDragueSolver:
         max|dz| falls below 1e-6 the z-step launches do nothing; `self.stop.converged()` polls it."""
         b = self.b
         self.iters += 1
-        vp = ops.pack_codes(self.codes(), None, b)                                       # adil.py:542
+        vp = ops.pack_codes(self.codes(defer=True), None, b)                             # adil.py:542
         xt = ops.synth(self.images, self.d, vp, b)                                       # adil.py:543-544
         _, _, g = input_gradient(self.model, xt, self.labels, self.loss, self.coeff, self.kappa, "mean")
-        _, gv = ops.grad(g, self.d, None, b, want_d=False, want_v=True)                  # dL/dv = g D
+        _, gv = ops.grad(g, self.d, None, b, want_d=False, want_v=True, defer_v=True)    # dL/dv = g D (summed by pack_codes)
         # dL/dz = (dL/dv) D_dagger is formed inside the kernel and consumed by AdamW(z) + clamp: never materialised (K8)
         ops.zstep_(self.z, self.m, self.s, self.dpt, ops.pack_codes(gv, None, b), b, self.sched.next(), -self.eps,
                    self.eps, stop=self.stop, dyn=dyn)
@@ -412,8 +418,7 @@ class DDragueSolver:
         before every replay; capture records and does not execute, so the counters are put back."""
         dev = self.z.device
         self._dyn = torch.zeros(3, 2, dtype=torch.float32, device=dev)
-        self._dyn_host = torch.zeros(8, 3, 2, dtype=torch.float32).pin_memory()
-        self._dyn_slot = 0
+        self._dyn_ring = ops.PinnedRing((3, 2), torch.float32)   # slots guarded by events: safe however far the host runs ahead
         t_sched, t_stop, iters = self.sched.t, self.stop.t, self.iters
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -423,12 +428,8 @@ class DDragueSolver:
         self._graph = graph
 
     def _replay(self) -> None:
-        slot = self._dyn_host[self._dyn_slot % 8]
-        self._dyn_slot += 1
-        for j in range(3):
-            h = self.sched.next()
-            slot[j, 0], slot[j, 1] = h.step_size, h.bc2_sqrt
-        self._dyn.copy_(slot, non_blocking=True)                 # ordered before the replay on the same stream
+        hs = [self.sched.next() for _ in range(3)]
+        self._dyn_ring.push(self._dyn, [(h.step_size, h.bc2_sqrt) for h in hs])     # ordered before the replay on the same stream
         self.stop.t += 3
         self.iters += 3
         self._graph.replay()

@@ -8,7 +8,7 @@ CPU path.
 from __future__ import annotations
 
 import math
-from ctypes import c_void_p
+from ctypes import byref, c_int, c_void_p
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -97,20 +97,44 @@ class AdamWSchedule:
     # -- hipGraph replay: the two step-dependent scalars live in device memory and are refreshed before each replay -- #
     def enable_device_scalars(self, device) -> Tensor:
         """A 2-float device buffer {step_size, bc2_sqrt} (the `dyn_scalars` of the AdamW entry points) fed through a ring
-        of pinned host slots, so that a launch recorded in a graph picks up the scalars of the step it is replayed for."""
+        of pinned host slots (PinnedRing), so that a launch recorded in a graph picks up the scalars of the step it is
+        replayed for."""
         self.dyn = torch.zeros(2, dtype=torch.float32, device=device)
-        self._pinned = torch.zeros(8, 2, dtype=torch.float32).pin_memory()
-        self._slot = 0
+        self._ring = PinnedRing((2,), torch.float32)
         return self.dyn
 
     def next_to_device(self) -> AdamWScalars:
         """next(), and a stream-ordered copy of its step-dependent scalars into the device buffer."""
         h = self.next()
-        slot = self._pinned[self._slot % 8]
-        self._slot += 1
-        slot[0], slot[1] = h.step_size, h.bc2_sqrt
-        self.dyn.copy_(slot, non_blocking=True)
+        self._ring.push(self.dyn, (h.step_size, h.bc2_sqrt))
         return h
+
+
+class PinnedRing:
+    """Small host values that recorded (hipGraph) launches read from device memory, refreshed before every replay.
+
+    A stream-ordered host-to-device copy reads its pinned source when the GPU REACHES it, not when it was queued, so the
+    source must not be rewritten before then: every slot carries an event recorded behind its copy, and a slot is only
+    reused after that event has completed (a host wait that happens only when the host is a whole ring of replays ahead
+    of the GPU).  Without it a free-running replay loop more than `slots` steps ahead handed the recorded AdamW kernels
+    the scalars of a LATER step."""
+
+    def __init__(self, shape, dtype, slots: int = 8):
+        self.host = torch.zeros((slots,) + tuple(shape), dtype=dtype).pin_memory()
+        self.events = [None] * slots
+        self.i = 0
+
+    def push(self, dst: Tensor, values) -> None:
+        """dst <- values (nested sequence of the slot's shape), ordered on the current stream before whatever follows."""
+        k = self.i % len(self.events)
+        self.i += 1
+        if self.events[k] is None:
+            self.events[k] = torch.cuda.Event()
+        else:
+            self.events[k].synchronize()                         # the copy that last read this slot has run
+        self.host[k].copy_(torch.as_tensor(values, dtype=self.host.dtype))
+        dst.copy_(self.host[k], non_blocking=True)
+        self.events[k].record()
 
 
 class StopTest:
@@ -144,24 +168,65 @@ class StopTest:
 
 
 # --------------------------------------------------------------------------- #
-def pack_codes(v: Tensor, index: Optional[Tensor], batch: Optional[int] = None, pos: Optional[Tensor] = None) -> Tensor:
+class SlabGrad:
+    """A (B,K) code gradient (or code matrix) that is still the per-workgroup partial sums ("slabs") of the ops.grad
+    call that produced it, inside that call's workspace: `nslabs` slabs of [rows][K] fp32 at `ptr`.  Its consumers —
+    adamw_l1ball_ and pack_codes — sum the slabs inside their own launch (same fixed order as the library's reduce
+    kernel, identical bits), so no reduction launch sits between producer and consumer.  Valid until the workspace of
+    the current stream is used again (the next ops.grad / gram / atom_norms call): consume it right away."""
+    __slots__ = ("ws", "ptr", "nslabs", "rows", "batch", "k")
+
+    def __init__(self, ws: Tensor, ptr: int, nslabs: int, rows: int, batch: int, k: int):
+        self.ws, self.ptr, self.nslabs, self.rows, self.batch, self.k = ws, ptr, nslabs, rows, batch, k
+
+    @property
+    def shape(self):
+        return (self.batch, self.k)
+
+
+def _slab_args(src):
+    if isinstance(src, SlabGrad):
+        return c_void_p(src.ptr), src.nslabs, src.rows
+    return c_void_p(0), 0, 0
+
+
+def pack_codes(v, index: Optional[Tensor], batch: Optional[int] = None, pos: Optional[Tensor] = None,
+               transposed: Optional[torch.dtype] = None):
     """vp [roundup(B,32)][roundup(K,16)] = zero-padded v[index] (adil.py:25 `self.v[index, :]`).
-    pos (int32, one entry per row of v, all -1): receives pos[index[b]] = b for adamw_l1ball_(..., reset_pos=True)."""
+    pos (int32, one entry per row of v, all -1): receives pos[index[b]] = b for adamw_l1ball_(..., reset_pos=True).
+    v may be a SlabGrad (the rows are then summed from the producer's slabs inside this launch; index / pos unused).
+    transposed = dtype of the gradient stream ops.grad will see: also returns vpt [code_rows(K)][roundup(B,32)] in that
+    dtype (fp32 / bf16), to be handed to ops.grad(vpt=...) — returns (vp, vpt) then."""
     lib = _lib.load()
-    _dev(v, "v", torch.float32)
-    k = v.shape[1]
-    if index is not None:
-        index = _dev(index.to(device=v.device, dtype=torch.int64), "index")
-        b = index.numel()
+    slabs = isinstance(v, SlabGrad)
+    if slabs:
+        if index is not None or pos is not None:
+            raise ValueError("pack_codes: a SlabGrad source has its rows in batch order (no index / pos)")
+        k, dev = v.k, v.ws.device
+        b = v.batch if batch is None else batch
+        if b != v.batch:
+            raise ValueError("pack_codes: batch does not match the SlabGrad")
     else:
-        b = v.shape[0] if batch is None else batch
+        _dev(v, "v", torch.float32)
+        k, dev = v.shape[1], v.device
+        if index is not None:
+            index = _dev(index.to(device=v.device, dtype=torch.int64), "index")
+            b = index.numel()
+        else:
+            b = v.shape[0] if batch is None else batch
     if pos is not None:
         _dev(pos, "pos", torch.int32)
         if pos.numel() != v.shape[0]:
             raise ValueError("pos must have one entry per row of v")
-    vp = torch.empty(_round_up(b, 32), _round_up(k, 16), dtype=torch.float32, device=v.device)
-    _lib.check(lib.adil_pack_codes(_ptr(v), _ptr(index), b, k, _ptr(vp), _ptr(pos), _stream()), "adil_pack_codes")
-    return vp
+    vp = torch.empty(_round_up(b, 32), _round_up(k, 16), dtype=torch.float32, device=dev)
+    vpt, code = None, 0
+    if transposed is not None:
+        code = stream_dtype_code(transposed)
+        vpt = torch.empty(lib.adil_grad_code_rows(k), _round_up(b, 32), dtype=transposed, device=dev)
+    sp, ns, sr = _slab_args(v)
+    _lib.check(lib.adil_pack_codes(None if slabs else _ptr(v), _ptr(index), b, k, _ptr(vp), _ptr(pos), _ptr(vpt), code,
+                                   sp, ns, sr, _stream()), "adil_pack_codes")
+    return vp if transposed is None else (vp, vpt)
 
 
 def gather_images(src: Tensor, index: Optional[Tensor], out: Optional[Tensor] = None,
@@ -223,8 +288,12 @@ def synth(x: Optional[Tensor], d: Tensor, vp: Tensor, batch: int, *, out: Option
 
 
 def grad(g: Tensor, d: Tensor, vp: Optional[Tensor], batch: int, *, want_d: bool = True, want_v: bool = True,
-         grad_d: Optional[Tensor] = None, accumulate_d: bool = False) -> Tuple[Optional[Tensor], Optional[Tensor]]:
-    """(grad_d (C,H,W,K), grad_vb (B,K)) of the synthesis for upstream gradient g (B x P)."""
+         grad_d: Optional[Tensor] = None, accumulate_d: bool = False, vpt: Optional[Tensor] = None,
+         defer_v: bool = False):
+    """(grad_d (C,H,W,K), grad_vb (B,K)) of the synthesis for upstream gradient g (B x P).
+    vpt: the transposed codes of pack_codes(..., transposed=g.dtype) (saves the launch that makes them here).
+    defer_v: the caller hands grad_vb straight to adamw_l1ball_ / pack_codes: when the kernels allow it (one row chunk)
+    the second result is a SlabGrad — the reduction then happens inside the consumer's launch — else the dense tensor."""
     lib = _lib.load()
     _dev(g, "g")
     _dev(d, "d", torch.float32)
@@ -243,15 +312,23 @@ def grad(g: Tensor, d: Tensor, vp: Optional[Tensor], batch: int, *, want_d: bool
         _dev(grad_d, "grad_d", torch.float32)
         if grad_d.shape != d.shape:
             raise ValueError("grad_d must have the dictionary's shape")
+        if vpt is not None:
+            _dev(vpt, "vpt", g.dtype)
+            if vpt.shape != (lib.adil_grad_code_rows(k), _round_up(batch, 32)):
+                raise ValueError("grad: vpt shape does not match (code_rows(K), roundup(B,32))")
     else:
-        grad_d = None
+        grad_d, vpt = None, None
     if want_v:
         gvb = torch.empty(batch, k, dtype=torch.float32, device=d.device)
     ws_bytes = lib.adil_grad_workspace_bytes(batch, p, k)
     ws = _workspace(d.device, ws_bytes)
-    _lib.check(lib.adil_grad(_ptr(g), _ptr(d), _ptr(vp), _ptr(grad_d), _ptr(gvb), batch, p, k,
-                             stream_dtype_code(g.dtype), int(bool(accumulate_d)), _ptr(ws), ws_bytes, _stream()),
-               "adil_grad")
+    nslabs = c_int(0)
+    _lib.check(lib.adil_grad(_ptr(g), _ptr(d), _ptr(vp), _ptr(vpt), _ptr(grad_d), _ptr(gvb), batch, p, k,
+                             stream_dtype_code(g.dtype), int(bool(accumulate_d)), _ptr(ws), ws_bytes,
+                             byref(nslabs) if (defer_v and want_v) else None, _stream()), "adil_grad")
+    if nslabs.value > 0:
+        gvb = SlabGrad(ws, ws.data_ptr() + lib.adil_grad_slab_offset(batch, p, k), nslabs.value, _round_up(batch, 32),
+                       batch, k)
     return grad_d, gvb
 
 
@@ -297,18 +374,21 @@ def zstep_(z: Tensor, m: Tensor, s: Tensor, dpinv_t: Tensor, gvp: Tensor, batch:
                "adil_zstep")
 
 
-def adamw_l1ball_(v: Tensor, grad_vb: Optional[Tensor], pos: Optional[Tensor], m: Tensor, s: Tensor, h: AdamWScalars,
+def adamw_l1ball_(v: Tensor, grad_vb, pos: Optional[Tensor], m: Tensor, s: Tensor, h: AdamWScalars,
                   radius: float, max_abs_delta: Optional[Tensor] = None, reset_pos: bool = False,
                   stop: Optional[StopTest] = None, dyn: Optional[Tensor] = None) -> None:
     """In-place AdamW on ALL rows of v (zero gradient outside the batch) + l1-ball projection
     (adil.py:186-187; radius < 0 skips the projection).  pos is the batch-slot table written by pack_codes; with
-    reset_pos the kernel hands it back all -1.  grad_vb None = no row of this v is in the batch (pos all -1)."""
+    reset_pos the kernel hands it back all -1.  grad_vb None = no row of this v is in the batch (pos all -1); a
+    SlabGrad (ops.grad(..., defer_v=True)) is summed inside the launch."""
     lib = _lib.load()
     for name, t in (("v", v), ("m", m), ("s", s)):
         _dev(t, name, torch.float32)
     n, k = v.shape
+    slabs = isinstance(grad_vb, SlabGrad)
     if grad_vb is not None:
-        _dev(grad_vb, "grad_vb", torch.float32)
+        if not slabs:
+            _dev(grad_vb, "grad_vb", torch.float32)
         if grad_vb.shape[1] != k:
             raise ValueError("adamw_l1ball_: shape mismatch")
     if pos is not None:
@@ -320,9 +400,10 @@ def adamw_l1ball_(v: Tensor, grad_vb: Optional[Tensor], pos: Optional[Tensor], m
     if m.shape != v.shape or s.shape != v.shape:
         raise ValueError("adamw_l1ball_: shape mismatch")
     dmax, skip, thr, clear = _stop_args(max_abs_delta, stop)
-    _lib.check(lib.adil_adamw_l1ball(_ptr(v), _ptr(grad_vb), _ptr(pos), int(bool(reset_pos)), _ptr(m), _ptr(s), n, k,
-                                     h.decay, h.b1, h.b2, h.eps, h.step_size, h.bc2_sqrt, float(radius),
-                                     dmax, skip, thr, clear, _ptr(dyn), _stream()), "adil_adamw_l1ball")
+    sp, ns, sr = _slab_args(grad_vb)
+    _lib.check(lib.adil_adamw_l1ball(_ptr(v), None if slabs else _ptr(grad_vb), _ptr(pos), int(bool(reset_pos)), _ptr(m),
+                                     _ptr(s), n, k, h.decay, h.b1, h.b2, h.eps, h.step_size, h.bc2_sqrt, float(radius),
+                                     dmax, skip, thr, clear, _ptr(dyn), sp, ns, sr, _stream()), "adil_adamw_l1ball")
 
 
 def l1ball_project_(x: Tensor, radius: float) -> Tensor:

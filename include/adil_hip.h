@@ -41,7 +41,10 @@ extern "C" {
 /* ABI version of this header; bumped on any signature change.  2: frozen-classifier entry points.  3: batch-slot table
  * written by adil_pack_codes and consumed + reset by adil_adamw_l1ball, adil_gather_images, adil_spd_inverse,
  * adil_synth_fp8.  4: device-side stop test arguments of adil_zstep / adil_adamw_l1ball.  5: dyn_scalars of the AdamW
- * entry points incl. adil_zstep (hipGraph replay of the learning step and of the inference iterations). */
+ * entry points incl. adil_zstep (hipGraph replay of the learning step and of the inference iterations).  6: the two
+ * helper launches of a gradient pass moved into their neighbours — adil_pack_codes can emit the transposed codes that
+ * adil_grad needs (`vpt`) and can take its rows from the grad_v partial sums ("slabs") of a preceding adil_grad;
+ * adil_grad can leave the reduction of those slabs to its consumer (`nslabs_out`); adil_adamw_l1ball consumes them. */
 int adil_abi_version(void);
 
 /* Largest K (atoms) the kernels support. */
@@ -50,12 +53,28 @@ int adil_max_atoms(void);
 /* Bytes of scratch adil_grad needs for this problem size. */
 size_t adil_grad_workspace_bytes(int B, int P, int K);
 
+/* Rows A of the transposed code matrix vpt [A][roundup(B,32)] that adil_grad contracts against (K rounded up to the
+ * atom tiling of the kernels: 32, 64 or 128); 0 for an unsupported K. */
+int adil_grad_code_rows(int K);
+
+/* Where, inside adil_grad's workspace, the grad_v partial sums live when their reduction is left to the consumer
+ * (adil_grad's nslabs_out): `*nslabs_out` slabs of [roundup(B,32)][K] fp32 each, starting this many bytes into ws. */
+size_t adil_grad_slab_offset(int B, int P, int K);
+
 /* Gather + pad the batch's code rows:  vp[b][k] = v[index[b]][k] (0 for k>=K, b>=B).
  * Replaces the advanced-indexing `self.v[index, :]` of Attack_dict_model.forward
  * (adil.py:25).  index may be NULL (rows 0..B-1, as adil.py:600 `range(n_img)`).
  * pos (optional, one int32 per row of v, all -1 on entry): pos[index[b]] = b — the batch-slot table that
- * adil_adamw_l1ball consumes; it is what autograd's scatter of the batch gradient into a dense (N,K) grad does. */
-int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, int32_t* pos, void* stream);
+ * adil_adamw_l1ball consumes; it is what autograd's scatter of the batch gradient into a dense (N,K) grad does.
+ * vpt (optional): also the transposed copy vpt[a][b] = vp[b][a], [adil_grad_code_rows(K)][roundup(B,32)] in element
+ * type vpt_dtype (ADIL_F32 / ADIL_BF16 = the dtype of the g stream adil_grad will be called with), zero padded:
+ * handing it to adil_grad saves that call a launch of its own.
+ * slabs / nslabs / slab_rows (nslabs > 0): the rows come from the partial sums a preceding adil_grad left in its
+ * workspace instead of from v (v, index ignored; pos must be NULL): row b = sum over the nslabs slabs, in the fixed
+ * order of the library's own reduction (bitwise the same values) — the codes `z D_dagger^T` and the code gradient
+ * `g D` of a DDrague iteration (adil.py:542, :551) reach the next kernel without a reduction launch in between. */
+int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, int32_t* pos, void* vpt,
+                    int vpt_dtype, const float* slabs, int nslabs, int slab_rows, void* stream);
 
 /* Batched image gather, the data step in front of the path (the DataLoader's per-item fetch + torch.stack + .to(device)
  * of adil.py:130-133,168-170 on a dataset that is resident in HBM): dst[b][:] = convert(src[index[b]][:]).
@@ -85,9 +104,14 @@ int adil_synth_fp8(const void* x, const float* d, const float* vp, void* out, in
  *     grad_vb (B x K)  = g D             if grad_vb != NULL
  * Replaces autograd's backward of the tensordot at adil.py:25 (loss.backward(), adil.py:185,
  * :281, :308, :606) and the forward contraction `tensordot(z, d_drg, ([1,2,3],[1,2,3]))`
- * (adil.py:542, :563) when called with g := z and d := D_dagger^T (grad_vb only). */
-int adil_grad(const void* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P, int K,
-              int dtype, int accumulate_d, void* ws, size_t ws_bytes, void* stream);
+ * (adil.py:542, :563) when called with g := z and d := D_dagger^T (grad_vb only).
+ * vpt (optional): the transposed codes written by adil_pack_codes (element type = dtype); NULL = made here.
+ * nslabs_out (optional, HOST int): the caller will consume grad_v through adil_adamw_l1ball / adil_pack_codes, which
+ * can sum the per-workgroup partial sums themselves.  When one row chunk covers the batch the reduction launch is
+ * skipped, *nslabs_out = number of slabs (at ws + adil_grad_slab_offset, valid until ws is next used) and grad_vb is
+ * left untouched; otherwise *nslabs_out = 0 and grad_vb is written as usual (grad_vb must be given either way). */
+int adil_grad(const void* g, const float* d, const float* vp, const void* vpt, float* grad_d, float* grad_vb, int B, int P,
+              int K, int dtype, int accumulate_d, void* ws, size_t ws_bytes, int* nslabs_out, void* stream);
 
 /* Fused AdamW step + box projection on a flat fp32 parameter (torch.optim.AdamW semantics):
  *     p *= decay ; m += (1-b1)(g-m) ; s = b2 s + (1-b2) g^2 ;
@@ -129,11 +153,13 @@ int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, const float* 
  * radius < 0 skips the projection.
  * Replaces optimise.step() + update_v (adil.py:186-187 with :29-31 and utils.py:21-41),
  * and the same pair in forward_supervised_AdamW (adil.py:609-610, :614); skip_if_below / skip_threshold / clear are the
- * device-side stop test described at adil_zstep (adil.py:614); dyn_scalars as in adil_adamw_clamp. */
+ * device-side stop test described at adil_zstep (adil.py:614); dyn_scalars as in adil_adamw_clamp.
+ * slabs / nslabs / slab_rows (nslabs > 0): the batch gradient is still in the partial sums of the preceding adil_grad
+ * (its nslabs_out): gradient row b = sum over the slabs, formed inside this launch; grad_vb is then ignored. */
 int adil_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, int reset_pos, float* m, float* s, int N, int K,
                       float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt, float radius,
                       float* max_abs_delta, const float* skip_if_below, float skip_threshold, float* clear,
-                      const float* dyn_scalars, void* stream);
+                      const float* dyn_scalars, const float* slabs, int nslabs, int slab_rows, void* stream);
 
 /* Row-wise Euclidean projection onto the l1 ball, in place: project_onto_l1_ball (utils.py:21-41). */
 int adil_l1ball_project(float* x, int N, int K, float radius, void* stream);

@@ -304,3 +304,36 @@ def test_main_load_image_follows_the_reference_transform(tmp_path):
     # a portrait image: the WIDTH becomes 256
     PIL.fromarray(arr.transpose(1, 0, 2)).save(path)
     assert main_cli.load_image(str(path)).shape == (3, 224, 224)
+
+
+def test_margin_loss_matches_the_reference_f_loss_fixture():
+    """The PRODUCT's f_loss (engine.margin_loss, ADIL.f_loss -> adil.py:103-112) against fixture G5, which holds the
+    reference's own values and gradients on random logits incl. the row whose other logits are all negative (the zeroed
+    label logit then wins the max — quirk Q5): value and gradient exact."""
+    from conftest import load_golden, t
+    from dl_attack_on_imagenet_amd import engine
+    z = load_golden("g5_floss")
+    lg = t(z["logits"]).clone().requires_grad_(True)
+    val = engine.margin_loss(lg, t(z["labels"]), float(z["kappa"]))
+    val.sum().backward()
+    assert torch.equal(val.detach(), t(z["value"]))
+    assert torch.equal(lg.grad, t(z["grad"]))
+    # attack_loss('logits') is its sum (adil.py:183), whatever the logits' dtype
+    tot = engine.attack_loss(t(z["logits"]).to(torch.bfloat16), t(z["labels"]), "logits", -1.0, float(z["kappa"]), "sum")
+    assert tot.dtype == torch.float32 and abs(float(tot) - float(t(z["value"]).sum())) < 0.5
+
+
+def test_demo_cast_loader_keeps_the_loader_interface():
+    """the bf16 demo path used to turn its DataLoader into a list, which lost `batch_size` (the
+    classifier's batch bucket) and `dataset` (the transfer evaluation's sample count)."""
+    import demo_dL_attack as demo
+    import performance as perf
+    ds = torch.utils.data.TensorDataset(torch.rand(7, 3, 4, 4), torch.arange(7))
+    loader = torch.utils.data.DataLoader(ds, batch_size=3, shuffle=False)
+    assert demo._cast_loader(loader, torch.float32) is loader
+    cast = demo._cast_loader(loader, torch.bfloat16)
+    assert perf._loader_batch_size(cast) == 3 and len(cast.dataset) == 7 and len(cast) == 3
+    for _ in range(2):                                             # re-iterable, like a DataLoader
+        got = list(cast)
+        assert [x.shape[0] for x, _ in got] == [3, 3, 1] and all(x.dtype == torch.bfloat16 for x, _ in got)
+        assert torch.equal(torch.cat([y for _, y in got]), torch.arange(7))

@@ -521,6 +521,51 @@ def test_graphed_learner_step_is_bit_identical():
         assert a.sched_d.t == b.sched_d.t == len(schedule)
 
 
+def test_graphed_learner_free_running_replays_match_eager():
+    """30 replays of the graphed step queued WITHOUT any host synchronisation while the GPU is kept busy (so the
+    host is dozens of replays — several rings of pinned scalar slots — ahead of the device) must still hand every
+    recorded AdamW launch the scalars of ITS step: D, V, the moments and the per-step fooled counts equal the eager loop
+    bit for bit.  Before the slots were guarded by events (ops.PinnedRing) a host more than 8 replays ahead overwrote a
+    slot before its copy had run.  Same for the DDrague solver's groups of three iterations."""
+    from dl_attack_on_imagenet_amd import engine, ops
+    from tinynet import make_tinynet
+    net = make_tinynet(4).to(DEV)
+    g = torch.Generator().manual_seed(19)
+    images = torch.rand(16, 3, 32, 32, generator=g).to(DEV)
+    index = torch.arange(16, device=DEV)
+    d0 = (-1 + 2 * torch.rand(3, 32, 32, 6, generator=g)).to(DEV)
+    v0 = ops.l1ball_project_(torch.rand(16, 6, generator=g).to(DEV), 0.3)
+    steps = 33
+    a = engine.DictionaryLearner(d0.clone(), v0.clone(), 0.3, 0.01, "logits")
+    fooled_a = [a.step(net, images, index)[1] for _ in range(steps)]
+    b = engine.DictionaryLearner(d0.clone(), v0.clone(), 0.3, 0.01, "logits")
+    fooled_b = [b.step_graphed(net, images, index)[1] for _ in range(3)]     # two eager warm-ups + the capturing call
+    busy = torch.randn(4096, 4096, device=DEV)
+    torch.cuda.synchronize()
+    for _ in range(60):                                   # ~100 ms of queued GPU work: the host runs far ahead below
+        busy = (busy @ busy).clamp_(-1, 1)
+    for _ in range(steps - 3):
+        fooled_b.append(b.step_graphed(net, images, index)[1])              # no .item(), no sync
+    assert b._graph is not None
+    torch.cuda.synchronize()
+    assert [int(f) for f in fooled_a] == [int(f) for f in fooled_b]
+    for x, y in ((a.d, b.d), (a.v, b.v), (a.m_d, b.m_d), (a.s_d, b.s_d), (a.m_v, b.m_v), (a.s_v, b.s_v)):
+        assert torch.equal(x, y)
+    # the inference solver: 11 groups of three iterations queued behind the same kind of backlog
+    dd = (-1 + 2 * torch.rand(3, 32, 32, 6, generator=g)).to(DEV)
+    eager = engine.DDragueSolver(net, images[:5], dd, 0.1, "logits").run(36)
+    gr = engine.DDragueSolver(net, images[:5], dd, 0.1, "logits")
+    for _ in range(3):
+        gr.iterate()
+    gr._capture()
+    for _ in range(60):
+        busy = (busy @ busy).clamp_(-1, 1)
+    for _ in range(11):
+        gr._replay()
+    torch.cuda.synchronize()
+    assert torch.equal(eager.z, gr.z) and torch.equal(eager.m, gr.m) and torch.equal(eager.s, gr.s)
+
+
 def test_integration_md_stub_runs_a_learning_step():
     """The ctypes stub printed in INTEGRATION.md is executed as it stands (only the library path is filled in) and drives
     one learning step through the C ABI; the result equals the product's DictionaryLearner step bit for bit.  Keeps the

@@ -716,3 +716,85 @@ def test_gram_full_size(k):
     close(gm, ref, 3e-6 * float(ref.abs().max()))
     close(gm, gm.t(), 3e-6 * float(ref.abs().max()))
     assert torch.equal(gm, ops().gram(d))
+
+
+# ----------------------------------------------------------------------------- ABI 6: helper launches folded into neighbours
+@pytest.mark.parametrize("b,k,hw,dt", [(512, 50, 56, torch.bfloat16), (500, 50, 64, torch.bfloat16), (37, 10, 56, torch.bfloat16),
+                                       (256, 50, 56, torch.float32), (70, 64, 32, torch.float32), (5, 3, 9, torch.float32),
+                                       (512, 100, 32, torch.bfloat16), (256, 100, 32, torch.float32), (97, 128, 24, torch.bfloat16)])
+def test_transposed_codes_and_deferred_slab_reduction_are_bit_neutral(b, k, hw, dt):
+    """ABI 6: (i) pack_codes' transposed copy is exactly vp^T in the stream dtype and grad_d computed from it equals the
+    grad_d of the call that transposes for itself, bit for bit; (ii) a grad_v left as per-workgroup partial sums
+    (ops.SlabGrad) and summed inside the consumer — pack_codes, adamw_l1ball_ — gives the bits of the dense route (the
+    library's own reduce kernel uses the same slab_sum order); slab counts with and without a tail of the 32-wide rounds
+    (56x56: 147 slabs = 4 rounds + 19; 64x64: 192 = 6 rounds; 9x9: 4)."""
+    o = ops()
+    g0 = torch.Generator().manual_seed(b * 7 + k + hw)
+    n = b + 9
+    d = (-1 + 2 * torch.rand(3, hw, hw, k, generator=g0)).to(DEV)
+    v = (torch.randn(n, k, generator=g0) * 0.01).to(DEV)
+    index = torch.randperm(n, generator=g0)[:b].to(DEV)
+    gup = torch.randn(b, 3, hw, hw, generator=g0).to(DEV).to(dt).contiguous()
+    vp = o.pack_codes(v, index, b)
+    vp2, vpt = o.pack_codes(v, index, b, transposed=dt)
+    assert torch.equal(vp, vp2)
+    rows = vpt.shape[0]
+    assert vpt.dtype == dt and rows >= vp.shape[1] and vpt.shape[1] == vp.shape[0]
+    assert torch.equal(vpt[:vp.shape[1]].float(), vp.t().to(dt).float()) and not bool(vpt[vp.shape[1]:].any())
+    gd_a, gv_a = o.grad(gup, d, vp, b)
+    gd_b, gv_b = o.grad(gup, d, vp, b, vpt=vpt)
+    assert torch.equal(gd_a, gd_b) and torch.equal(gv_a, gv_b)
+    # deferred reduction, fused pass and grad_v-only pass
+    for want_d in (True, False):
+        _, dense = o.grad(gup, d, vp if want_d else None, b, want_d=want_d)
+        _, lazy = o.grad(gup, d, vp if want_d else None, b, want_d=want_d, defer_v=True)
+        if isinstance(lazy, o.SlabGrad):
+            assert lazy.shape == (b, k) and lazy.nslabs > 0
+            packed = o.pack_codes(lazy, None, b)
+            assert torch.equal(packed, o.pack_codes(dense, None, b))
+            _, lazy = o.grad(gup, d, vp if want_d else None, b, want_d=want_d, defer_v=True)    # same workspace, same values
+            p2, p2t = o.pack_codes(lazy, None, b, transposed=torch.float32)
+            assert torch.equal(p2, packed) and torch.equal(p2t[:packed.shape[1]], packed.t())
+        else:
+            assert torch.equal(lazy, dense)                       # more than one row chunk: reduced inside adil_grad
+        # through AdamW + projection on all n rows (slot table from pack_codes)
+        res = []
+        for defer in (False, True):
+            vv, m, s = v.clone(), torch.zeros_like(v), torch.zeros_like(v)
+            pos = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+            sched = o.AdamWSchedule(0.01)
+            for _ in range(2):
+                o.pack_codes(vv, index, b, pos=pos)
+                _, gv = o.grad(gup, d, vp if want_d else None, b, want_d=want_d, defer_v=defer)
+                o.adamw_l1ball_(vv, gv, pos, m, s, sched.next(), 8 / 255, reset_pos=True)
+            res.append((vv, m, s))
+            assert int((pos != -1).sum()) == 0
+        for x, y in zip(*res):
+            assert torch.equal(x, y)
+    # no slot table: row n <-> gradient row n (forward_supervised_AdamW's call)
+    _, lazy = o.grad(gup, d, None, b, want_d=False, defer_v=True)
+    _, dense = o.grad(gup, d, None, b, want_d=False)
+    out = []
+    for gsrc in (dense, lazy):
+        vv = v[:b].clone()
+        m, s = torch.zeros_like(vv), torch.zeros_like(vv)
+        if gsrc is lazy and isinstance(lazy, o.SlabGrad):
+            _, gsrc = o.grad(gup, d, None, b, want_d=False, defer_v=True)
+        o.adamw_l1ball_(vv, gsrc, None, m, s, o.AdamWSchedule(0.01).next(), 8 / 255)
+        out.append(vv)
+    assert torch.equal(out[0], out[1])
+
+
+def test_deferred_reduction_sums_match_the_oracle_at_full_size():
+    """Full-size check of the consumer-side reduction (ResNet-sized images, 512 bf16 rows, 50 atoms: 236 slabs): the codes
+    pack_codes forms from the slabs equal g D of the fp64 oracle on the bf16-rounded operands."""
+    o = ops()
+    g0 = torch.Generator().manual_seed(3)
+    b, k = 512, 50
+    d = (-1 + 2 * torch.rand(3, 224, 224, k, generator=g0)).to(DEV)
+    gup = (torch.randn(b, 3, 224, 224, generator=g0) * 1e-3).to(DEV).to(torch.bfloat16)
+    _, lazy = o.grad(gup, d, None, b, want_d=False, defer_v=True)
+    assert isinstance(lazy, o.SlabGrad) and lazy.nslabs > 200
+    got = o.pack_codes(lazy, None, b)[:b, :k]
+    ref = gup.double().flatten(1) @ d.to(torch.bfloat16).double().reshape(-1, k)
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7

@@ -29,12 +29,25 @@ for dt, s in ((torch.bfloat16, 2), (torch.float32, 4)):
     out = torch.empty_like(x); gd = torch.empty_like(d)
     rows = []
     t = timeit(lambda: ops.synth(x, d, vp, B, out=out)); rows.append(("synth", t, 2 * B * P * s + P * K * 4))
-    t = timeit(lambda: ops.grad(g, d, vp, B, grad_d=gd)); rows.append(("grad d+v", t, B * P * s + 2 * P * K * 4))
+    t = timeit(lambda: ops.grad(g, d, vp, B, grad_d=gd)); rows.append(("grad d+v (stand-alone: + transpose + reduce launches)", t, B * P * s + 2 * P * K * 4))
+    # the learning step's own sequence (engine.DictionaryLearner): the transposed codes come from pack_codes, the slabs
+    # of grad_v are summed inside adamw_l1ball_
+    vv, mv, sv = v.clone(), torch.zeros_like(v), torch.zeros_like(v)
+    pos = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    idx = torch.arange(B, device=dev)
+    hv = ops.AdamWSchedule(0.01).next()
+    def step_sequence():
+        vq, vqt = ops.pack_codes(vv, idx, B, pos=pos, transposed=dt)
+        _, gv = ops.grad(g, d, vq, B, grad_d=gd, vpt=vqt, defer_v=True)
+        ops.adamw_l1ball_(vv, gv, pos, mv, sv, hv, 8 / 255, reset_pos=True)
+    t = timeit(step_sequence); rows.append(("pack + grad d+v + adamw_l1ball (step sequence)", t, B * P * s + 2 * P * K * 4 + 9 * B * K * 4))
+    vq, vqt = ops.pack_codes(vv, idx, B, transposed=dt)
+    t = timeit(lambda: ops.grad(g, d, vq, B, grad_d=gd, vpt=vqt, defer_v=True)); rows.append(("grad d+v (in-step form: one launch)", t, B * P * s + 2 * P * K * 4))
     t = timeit(lambda: ops.grad(g, d, vp, B, want_v=False, grad_d=gd)); rows.append(("grad d only", t, B * P * s + P * K * 4))
     t = timeit(lambda: ops.grad(g, d, None, B, want_d=False)); rows.append(("grad v only", t, B * P * s + P * K * 4))
     t = timeit(lambda: out.copy_(x)); rows.append(("torch copy (ref)", t, 2 * B * P * s))
     for name, t, byt in rows:
-        print(f"{str(dt):16s} {name:18s} {t*1e3:9.1f} us   {byt/t/1e6:8.1f} GB/s algorithmic", flush=True)
+        print(f"{str(dt):16s} {name:52s} {t*1e3:9.1f} us   {byt/t/1e6:8.1f} GB/s algorithmic", flush=True)
 m, sq = torch.zeros_like(d), torch.zeros_like(d)
 h = ops.AdamWSchedule(0.01).next()
 gd = torch.randn_like(d)
@@ -50,9 +63,9 @@ pinv = engine.PseudoInverse(d)
 dpt = pinv.d_pinv_t
 hz = ops.AdamWSchedule(1e-2).next()
 def iteration():
-    _, vc = ops.grad(z, dpt, None, B, want_d=False)            # v = z D_dagger^T
+    _, vc = ops.grad(z, dpt, None, B, want_d=False, defer_v=True)   # v = z D_dagger^T (summed by pack_codes)
     xt = ops.synth(x32, d, ops.pack_codes(vc, None, B), B)      # x + D v
-    _, gv = ops.grad(g32, d, None, B, want_d=False)            # dL/dv = g D
+    _, gv = ops.grad(g32, d, None, B, want_d=False, defer_v=True)   # dL/dv = g D
     ops.zstep_(z, mz, sz, dpt, ops.pack_codes(gv, None, B), B, hz, -8 / 255, 8 / 255)
 t = timeit(iteration, n=10)
 alg = 9 * B * P * 4 + 4 * P * K * 4
