@@ -251,8 +251,7 @@ def spawn_ranks(args):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
+    env = dict(os.environ)         # HSA_ENABLE_IPC_MODE_LEGACY is set by dist.init_from_env inside every rank, whoever launched it
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
     return subprocess.run(cmd, env=env).returncode
 
@@ -291,7 +290,7 @@ def main():
     v = ops.l1ball_project_(torch.rand(B, K, generator=gen).to(dev), eps)
     # ADIL_FORCE_REDUCER=1 exercises the RCCL path (process group, all-reduce of grad_d) even with one rank
     force = os.environ.get("ADIL_FORCE_REDUCER") == "1" and torch.distributed.is_initialized()
-    reducer = adist.DictGradReducer() if (world > 1 or force) else None
+    reducer = adist.DictGradReducer(timing=True) if (world > 1 or force) else None
     if args.mode == "inference":
         solver = engine.DDragueSolver(model, x, d, eps, args.loss, False, 50.0)          # Gram / pseudo-inverse: once per call
 
@@ -318,6 +317,8 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    if reducer is not None:
+        reducer.reset_timing()                                # brackets of the timed steps only
     timer.enabled = True
     t0 = time.perf_counter()
     fooled = None
@@ -326,6 +327,13 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    # what the collective cost: backend, world size, mean start -> wait bracket of the step's all-reduce (HIP events on
+    # the compute stream; contains the code-row update that runs underneath); a 1-rank run has no collective
+    collective = reducer.describe() if reducer is not None else {
+        "backend": None, "world_size": world, "bytes_per_allreduce": 0,
+        adist.IPC_ENV: os.environ.get(adist.IPC_ENV)}
+    if reducer is not None:
+        reducer.timing = False
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         elapsed = float(adist.all_reduce_(tmax, torch.distributed.ReduceOp.MAX))
@@ -386,6 +394,7 @@ def main():
                                  f"stride1_3x3_convs=adil_conv3x3",
                    "global_batch": world * B, "atoms": K, "inner_iters": args.steps,
                    "parallelism": f"dp{world}: images+codes sharded, D replicated, 1 all-reduce(grad_d)/step",
+                   "collective": collective,
                    ("train_fooling_rate_last_step" if args.mode == "learn" else "fooling_rate_after_timed_iterations"): fool_rate},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -64,14 +64,15 @@ def spawn_ranks(args):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={max(1, n)}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.run(cmd, env=env).returncode
+    return subprocess.run(cmd, env=dict(os.environ)).returncode      # HSA_ENABLE_IPC_MODE_LEGACY: dist.init_from_env, in every rank
 
 
 def main(args):
     if args.distributed and "WORLD_SIZE" not in os.environ and torch.cuda.device_count() > 1:
         raise SystemExit(spawn_ranks(args))
+    if args.distributed:
+        from dl_attack_on_imagenet_amd import dist as adist
+        os.environ.setdefault(adist.IPC_ENV, "0")       # before this process's first HIP call (see dist.init_from_env)
     if not torch.cuda.is_available():
         print('Check cuda setting for model training on ImageNet')       # demo_dL_attack.py:30-32
         return

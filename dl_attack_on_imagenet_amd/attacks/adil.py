@@ -43,10 +43,10 @@ class Attack_dict_model(nn.Module):
         self.d.data.clamp_(min=-1, max=1)
 
 
-def engine_solve_codes(atk, images, d, mean_over=None):
+def engine_solve_codes(atk, images, d, mean_over=None, reducer=None):
     """forward_supervised_AdamW in 'train' mode on one rank's shard of a validation batch."""
     return engine.solve_codes_adamw(atk.model, images, d, atk.eps, atk.loss, atk.targeted, atk.kappa, atk.norm, 'train',
-                                    mean_over=mean_over)
+                                    mean_over=mean_over, reducer=reducer)
 
 
 class ADIL(Attack):
@@ -314,7 +314,7 @@ class ADIL(Attack):
             vfooled = torch.zeros((), dtype=torch.int64, device=self.device)
             for gb in vorder:
                 mine = [i - vlo for i in owned_rows(gb, vlo, vhi)]
-                vfooled += engine_solve_codes(self, val_res.gather(mine), learner.d, mean_over=len(gb))
+                vfooled += engine_solve_codes(self, val_res.gather(mine), learner.d, mean_over=len(gb), reducer=reducer)
             return torch.tensor(reducer.sum_scalars(vfooled)[0] / len(val), device=self.device)
 
         loss_all, fooling_rate_all = [], []

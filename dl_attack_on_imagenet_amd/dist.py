@@ -8,6 +8,7 @@ SUM (not mean) reproduces the reference's `reduction='sum'` loss (adil.py:136)."
 from __future__ import annotations
 
 import os
+import warnings
 from typing import List, Optional, Tuple
 
 import torch
@@ -22,13 +23,25 @@ def local_device_index(local_rank: int) -> int:
     return local_rank
 
 
+IPC_ENV = "HSA_ENABLE_IPC_MODE_LEGACY"
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, world_size, local_rank) from torchrun's env; initialises the default process group when
     WORLD_SIZE > 1.  backend: argument, else $ADIL_DIST_BACKEND, else 'nccl' (= RCCL on ROCm) when a GPU is
-    present, else 'gloo'."""
+    present, else 'gloo'.
+
+    One environment for every launch form (bench.py / demo_dL_attack.py starting their own ranks, or a driver calling
+    `python -m torch.distributed.run` itself): HSA_ENABLE_IPC_MODE_LEGACY=0 is set HERE, before this process makes its
+    first HIP call, unless the caller exported a value.  Source: the deployment notes of this MI355X pool — the host
+    driver only supports dmabuf IPC, and with the legacy IPC mode RCCL's (and torch's) cross-process sharing of device
+    memory fails with `hipIpcGetMemHandle: invalid argument`.  The ROCr runtime reads the variable when it is
+    initialised, so it has to be in place before `torch.cuda.*` touches the device — callers invoke init_from_env first."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or os.environ.get("ADIL_FORCE_REDUCER") == "1":
+        os.environ.setdefault(IPC_ENV, "0")
     if (world > 1 or os.environ.get("ADIL_FORCE_REDUCER") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -65,14 +78,33 @@ def global_epoch_batches(n: int, batch_size: int, world: int, seed: int, epoch: 
     batch_size // world rows, so a global batch is balanced across ranks by construction and all ranks take the SAME
     number of steps, ceil(largest shard / chunk): a rank whose shard is exhausted contributes an empty chunk and
     still joins that step's all-reduce (no collective can ever pair with a different one)."""
-    chunk = max(1, batch_size // world)
+    if batch_size < world:
+        warnings.warn(f"global batch {batch_size} < {world} ranks: every rank still takes one image per step, "
+                      f"so the global batch is {world}", stacklevel=2)
+    # rank r takes batch_size // world rows per step and the remainder batch_size % world is dealt out round-robin,
+    # continuing from step to step (8 ranks, batch 100: ranks 0-3 take 13 in even steps, ranks 4-7 in odd ones), so the
+    # global batch is `batch_size` exactly and equal shards run out together: 1000 images = 10 steps of 100, like the
+    # single-process learner (batch_size // world alone gave 11 steps of 96)
+    base, rem = divmod(batch_size, world)
+    if base == 0:
+        base, rem = 1, 0
     perms = []
     for r in range(world):
         lo, hi = shard_bounds(n, r, world)
         g = torch.Generator().manual_seed(1_000_003 * (seed + 1) + 7919 * epoch + r)
         perms.append((lo + torch.randperm(hi - lo, generator=g)).tolist())
-    steps = max((len(p) + chunk - 1) // chunk for p in perms)
-    return [[i for p in perms for i in p[s * chunk:(s + 1) * chunk]] for s in range(steps)]
+    taken = [0] * world
+    batches, s = [], 0
+    while any(taken[r] < len(perms[r]) for r in range(world)):
+        first = (s * rem) % world
+        batch = []
+        for r in range(world):
+            c = base + (1 if (r - first) % world < rem else 0)
+            batch += perms[r][taken[r]:taken[r] + c]
+            taken[r] += c
+        batches.append(batch)
+        s += 1
+    return batches
 
 
 def _staged(t: torch.Tensor, group=None) -> bool:
@@ -93,11 +125,33 @@ def all_reduce_(t: torch.Tensor, op=dist.ReduceOp.SUM, group=None) -> torch.Tens
 class DictGradReducer:
     """The single collective of a learning step: grad_d <- sum over ranks (in place)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, timing: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("DictGradReducer needs an initialised process group (see init_from_env)")
         self.group = group
         self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.timing = bool(timing)               # bench.py: HIP-event bracket around every start -> wait
+        self._brackets, self._open, self.bytes_per_call = [], None, 0
+        self.saw_async_work = False              # the asynchronous (RCCL) branch of all_reduce_start has been taken
+
+    # -- measurement (bench.py's config.collective) ------------------------------------------------------------------ #
+    def describe(self) -> dict:
+        """Backend, world size and — with timing on — the mean time between the start of the step's all-reduce and the
+        point where the compute stream has passed its wait (HIP events on the compute stream: it contains the AdamW +
+        projection of the code rows that runs underneath, i.e. it is an upper bound of what the collective can cost a
+        step), over the brackets recorded so far.  Call after a device synchronisation."""
+        out = {"backend": self.backend, "world_size": self.world, "bytes_per_allreduce": self.bytes_per_call,
+               IPC_ENV: os.environ.get(IPC_ENV)}
+        if self._brackets:
+            ms = [a.elapsed_time(b) for a, b in self._brackets]
+            out["allreduce_ms_start_to_wait_mean"] = sum(ms) / len(ms)
+            out["allreduce_ms_start_to_wait_max"] = max(ms)
+            out["allreduce_brackets"] = len(ms)
+        return out
+
+    def reset_timing(self) -> None:
+        self._brackets, self._open = [], None
 
     def all_reduce_(self, grad_d: torch.Tensor) -> torch.Tensor:
         return all_reduce_(grad_d, dist.ReduceOp.SUM, self.group)
@@ -106,10 +160,28 @@ class DictGradReducer:
         """Start the step's collective and return a handle whose .wait() orders the CURRENT stream behind it (RCCL runs on
         its own stream): the caller puts the work that does not need the reduced gradient — AdamW + projection of the code
         rows — between start and wait.  The gloo rehearsal path reduces synchronously and returns None."""
+        self.bytes_per_call = grad_d.numel() * grad_d.element_size()
+        e0 = None
+        if self.timing and grad_d.is_cuda:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         if _staged(grad_d, self.group):
             all_reduce_(grad_d, dist.ReduceOp.SUM, self.group)
-            return None
-        return dist.all_reduce(grad_d, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = None
+        else:
+            work = dist.all_reduce(grad_d, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.saw_async_work = True
+        return _Pending(self, work, e0)
+
+    def max_(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place MAX over ranks of a small tensor (the stop slot of a sharded solver)."""
+        return all_reduce_(t, dist.ReduceOp.MAX, self.group)
+
+    def _closed(self, e0) -> None:
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._brackets.append((e0, e1))
 
     def sum_scalars(self, *values) -> List[float]:
         """Per-epoch bookkeeping (loss, fooled counts): mirrors dist.reduce at adil.py:418-419."""
@@ -137,3 +209,16 @@ class DictGradReducer:
         parts = [torch.empty_like(pad) for _ in counts]
         dist.all_gather(parts, pad, group=self.group)
         return torch.cat([p[:c] for p, c in zip(parts, counts)]).to(rows.device)
+
+
+class _Pending:
+    """Handle of a started all-reduce: .wait() orders the current stream behind it (the host does not block)."""
+    __slots__ = ("reducer", "work", "e0")
+
+    def __init__(self, reducer: DictGradReducer, work, e0):
+        self.reducer, self.work, self.e0 = reducer, work, e0
+
+    def wait(self) -> None:
+        if self.work is not None:
+            self.work.wait()
+        self.reducer._closed(self.e0)

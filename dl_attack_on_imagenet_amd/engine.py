@@ -302,11 +302,16 @@ class DictionaryLearner:
 # --------------------------------------------------------------------------- #
 def solve_codes_adamw(model, images: Tensor, d: Tensor, eps: float, loss: str = "ce", targeted: bool = False,
                       kappa: float = 50.0, norm: str = "linf", mode: str = "train", max_iter: int = 100,
-                      labels: Optional[Tensor] = None, return_codes: bool = False, mean_over: Optional[int] = None):
+                      labels: Optional[Tensor] = None, return_codes: bool = False, mean_over: Optional[int] = None,
+                      reducer: Optional[DictGradReducer] = None):
     """forward_supervised_AdamW (adil.py:569-623): per-image codes with D fixed.
     mode 'train' -> fooled count (0-d tensor); otherwise clamp(images + D proj(v), 0, 1).
     mean_over: size of the GLOBAL batch when `images` is one rank's shard of it — the reference's mean-reduced CE
-    (adil.py:578) then divides by that size, so a sharded validation solves the same problem as an unsharded one."""
+    (adil.py:578) then divides by that size, so a sharded validation solves the same problem as an unsharded one.
+    reducer (with mean_over): the stop test of adil.py:614 is on max|dv| of the WHOLE batch, so the shards' stop slots
+    are max-reduced over the ranks after every iteration (one float; the kernels of the next iteration read the global
+    value) — every rank, also one that owns no image of this batch, runs the same number of iterations and issues
+    the same collectives."""
     images = _flat_images(images)
     b = images.shape[0]
     p, k = ops.dict_shape(d)
@@ -315,6 +320,8 @@ def solve_codes_adamw(model, images: Tensor, d: Tensor, eps: float, loss: str = 
     if mean_over is not None and mean_over != b:
         coeff, ce_reduction = coeff / float(mean_over), "sum"
     if b == 0:
+        if reducer is not None:
+            _idle_rank_stop_loop(images.device, reducer, int(max_iter))
         if mode == "train":
             return torch.zeros((), dtype=torch.int64, device=images.device)
         return images.clone()
@@ -332,6 +339,8 @@ def solve_codes_adamw(model, images: Tensor, d: Tensor, eps: float, loss: str = 
         _, _, g = input_gradient(model, xt, labels, loss, coeff, kappa, ce_reduction)
         _, gvb = ops.grad(g, d, None, b, want_d=False, want_v=True, defer_v=True)
         ops.adamw_l1ball_(v, gvb, None, m, s, sched.next(), eps, stop=stop)                # adil.py:609-610
+        if reducer is not None:
+            reducer.max_(stop.last_slot())                     # the batch's max|dv|, not the shard's
         if (it + 1) % STOP_POLL == 0 and stop.converged():     # launches after the converged one are no-ops
             break
     vproj = v.clone()
@@ -348,6 +357,17 @@ def solve_codes_adamw(model, images: Tensor, d: Tensor, eps: float, loss: str = 
     if return_codes:
         return res, dict(v=v, iters=iters, labels=labels)
     return res
+
+
+def _idle_rank_stop_loop(device, reducer: DictGradReducer, max_iter: int) -> None:
+    """A rank that owns no image of a sharded validation batch: it has nothing to solve but must pair up with the other
+    ranks' per-iteration max-reduction of the stop slot, and leave the loop at the same poll point as they do."""
+    stop = ops.StopTest(device, 1e-6)
+    for it in range(max_iter):
+        stop.idle_iteration()
+        reducer.max_(stop.last_slot())
+        if (it + 1) % STOP_POLL == 0 and stop.converged():
+            break
 
 
 class PseudoInverse:

@@ -162,6 +162,17 @@ class StopTest:
         self.slots.copy_(torch.tensor([0.0, 0.0, 3.0e38], dtype=torch.float32))
         self.t = 0
 
+    def last_slot(self) -> Tensor:
+        """1-element view of the slot the last launched iteration accumulated its max|delta| into (for a max-reduction
+        over ranks when the iterate is sharded: the next launch then tests the global value)."""
+        i = (self.t - 1) % 3
+        return self.slots[i:i + 1]
+
+    def idle_iteration(self) -> None:
+        """What a launch does to the slots when it has no rows: nothing to accumulate, clear the successor's slot."""
+        self.slots[(self.t + 1) % 3] = 0.0
+        self.t += 1
+
     def converged(self) -> bool:
         """True once the last launched iteration (or an earlier one) moved nothing by the threshold or more."""
         return self.t > 0 and float(self.slots[(self.t - 1) % 3]) < self.threshold

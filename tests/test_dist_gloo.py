@@ -113,7 +113,7 @@ def _install_oracle_backend(O):
                 yield index, self.images[index]
 
     def solve_codes(model, images, d, eps, loss="ce", targeted=False, kappa=50.0, norm="linf", mode="train",
-                    max_iter=100, labels=None, return_codes=False, mean_over=None):
+                    max_iter=100, labels=None, return_codes=False, mean_over=None, reducer=None):
         assert loss == "logits", "the stand-in ignores mean_over, which only matters for the mean-reduced CE"
         if images.shape[0] == 0:
             return torch.zeros((), dtype=torch.int64)
@@ -173,8 +173,9 @@ def test_product_distributed_learner_matches_single_process_global_batch(world, 
             vexplicit = [adist.global_epoch_batches(N_VAL, BATCH, world, 6, e) for e in range(STEPS)]
             sizes = [len(b) for b in explicit[0]]
             assert sorted(i for b in explicit[0] for i in b) == list(range(N_IMG))      # one epoch = every image once
-            # 2 ranks: 9 + 8 images in chunks of 3; 4 ranks: 5 + 4 + 4 + 4 images in chunks of 1 — equal step count, ragged tail
-            assert sizes == ([6, 6, 5] if world == 2 else [4, 4, 4, 4, 1])
+            # 2 ranks: 9 + 8 images in chunks of 3; 4 ranks: 5 + 4 + 4 + 4 images in chunks of 1 or 2 (the remainder 6 % 4
+            # goes round the ranks): the global batch is the requested 6, equal step count, ragged tail
+            assert sizes == [6, 6, 5]
         # single-process reference at the same GLOBAL batches
         ref = O.learn_dictionary_a(net, images, d0, v0, explicit, EPS, 0.01, "logits", False, 50.0, val_images=val,
                                    val_batches=vexplicit)
@@ -202,6 +203,15 @@ def test_global_epoch_batches_equal_steps_and_ownership():
     assert [len(x) for x in per_rank[1]][-1] == 0                  # rank 1 (500 images) is empty on the last step ...
     assert [len(x) for x in per_rank[0]][-1] == 1                  # ... where rank 0 (501) still has one image
     assert adist.global_epoch_batches(1001, 100, 2, 0, 0) == batches                    # deterministic
+    # a batch size that is no multiple of the world size keeps its size (100 over 8 ranks used to give 96) and
+    # equal shards run out together: 1000 images = 10 steps of exactly 100, every image once
+    b8 = adist.global_epoch_batches(1000, 100, 8, 0, 0)
+    assert [len(b) for b in b8] == [100] * 10 and sorted(i for b in b8 for i in b) == list(range(1000))
+    own = [[len(adist.owned_rows(b, *adist.shard_bounds(1000, r, 8))) for r in range(8)] for b in b8]
+    assert all(sorted(row) == [12] * 4 + [13] * 4 for row in own)
+    with pytest.warns(UserWarning):
+        tiny = adist.global_epoch_batches(20, 3, 8, 0, 0)                               # fewer images per step than ranks
+    assert sorted(i for b in tiny for i in b) == list(range(20)) and len(tiny[0]) == 8
     assert adist.global_epoch_batches(1001, 100, 2, 0, 1) != batches                    # reshuffled every epoch
 
 

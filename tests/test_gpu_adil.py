@@ -2,6 +2,7 @@
 golden vectors generated from the reference: learned D, per-image V, adversarial images within a stated fp32
 tolerance, argmax label decisions / fooling counts bit-exact."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -353,6 +354,62 @@ def test_single_rank_rccl_reducer_is_bitwise_neutral(tmp_path):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def _two_rank_learner_run(tmp_path, env_extra):
+    """Start 2 fresh child ranks of tests/dist_learn_worker.py (python -m torch.distributed.run, rendezvous on 127.0.0.1)
+    and compare with the single-process learner of THIS process at the same global batches."""
+    import json
+    import socket
+    import subprocess
+    from attacks import ADIL
+    from dist_learn_problem import IndexedImages, problem
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, **env_extra)
+    env.pop("ADIL_FORCE_REDUCER", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(here, "dist_learn_worker.py"), str(tmp_path)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    infos = [json.load(open(tmp_path / f"info_rank{k}.json")) for k in range(2)]
+    d_ranks = [torch.load(tmp_path / f"d_rank{k}.pt") for k in range(2)]
+    assert torch.equal(d_ranks[0], d_ranks[1])                          # the replicated dictionary never diverges
+    p = problem()
+    ADIL(p["net"].to(DEV), data_train=IndexedImages(p["images"]), data_val=IndexedImages(p["val"]), model_name="sp",
+         dict_dir=str(tmp_path / "dicts"), **p["kw"])
+    dp = torch.load(tmp_path / "dicts" / "ImageNet_dp2.bin", map_location="cpu")
+    sp = torch.load(tmp_path / "dicts" / "ImageNet_sp.bin", map_location="cpu")
+    assert torch.equal(dp[0], d_ranks[0])
+    # the two ranks sum their partial grad_d in a different order than one pass over the global batch: fp32 rounding only
+    assert float((dp[0] - sp[0]).abs().max()) <= 2e-5 and float((dp[1] - sp[1]).abs().max()) <= 2e-5
+    assert dp[1].shape == sp[1].shape and list(dp[3]) == list(sp[3])     # V gathered from both ranks; fooling rates per epoch
+    assert max(abs(a - b) for a, b in zip(dp[2], sp[2])) <= 1e-4 * max(1.0, max(abs(a) for a in sp[2]))
+    assert abs(float(dp[4]) - float(sp[4])) < 1e-6                        # sharded validation (global stop test)
+    return infos
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one RCCL rank per device")
+def test_two_rank_rccl_learner_matches_single_process(tmp_path):
+    """the RCCL path with MORE THAN ONE rank — 2 fresh child ranks, one GPU each, backend 'nccl' (no gloo,
+    no shared device): learn_dictionary_distributed == learn_dictionary_a at the global batches, D bit-identical across
+    ranks, and the asynchronous all_reduce_start / wait branch (engine.py: overlap with the code-row update) is the one
+    that ran.  Skipped on the one-GPU boxes; the same worker runs there as the rehearsal below."""
+    infos = _two_rank_learner_run(tmp_path, {})
+    assert [i["backend"] for i in infos] == ["nccl", "nccl"] and all(i["world_size"] == 2 for i in infos)
+    assert all(i["async_work"] for i in infos)
+    assert {i["device"] for i in infos} == {"cuda:0", "cuda:1"}
+    assert all(i["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for i in infos)
+
+
+def test_two_rank_learner_rehearsal_on_one_gpu(tmp_path):
+    """The same worker as the RCCL test on a one-GPU box: two ranks share the card and exchange through gloo
+    (ADIL_DIST_BACKEND=gloo ADIL_SHARE_GPU=1; RCCL refuses two ranks on one device).  Everything but the transport is the
+    shipped path: HIP kernels, ownership, the sharded validation with its max-reduced stop slot, the padded gather of V."""
+    infos = _two_rank_learner_run(tmp_path, {"ADIL_DIST_BACKEND": "gloo", "ADIL_SHARE_GPU": "1"})
+    assert [i["backend"] for i in infos] == ["gloo", "gloo"] and all(i["world_size"] == 2 for i in infos)
 
 
 @pytest.mark.parametrize("tag,norm,optim", [("linf_adam", "linf", "adam"), ("l2_sgd", "l2", "sgd")])
