@@ -175,6 +175,23 @@ class ADIL(Attack):
     def _val_due(self, iteration):
         return self._val_every > 0 and (iteration + 1) % self._val_every == 0
 
+    def _skip_validation(self, val, batch_size):
+        """An epoch whose validation is skipped (val_every) still draws what the validation loader's iterator would have
+        drawn from the global torch RNG (its base seed + the sampler's seed, loader.shuffled_batches), so the training
+        shuffle of every later epoch — and with it the dictionary file — is the same for any val_every."""
+        self._rng_before_skip = None
+        if val is not None and self._val_batches is None:
+            self._rng_before_skip = torch.get_rng_state()        # the end-of-run validation replays exactly these draws
+            shuffled_batches(len(val), batch_size)
+
+    def _final_validation(self, val, epoch, d, batch_size):
+        """The stored validation value is the last epoch's (adil.py:199-205, :210); when that epoch's validation was
+        skipped it runs here, with the shuffle the skipped call would have used."""
+        state = getattr(self, "_rng_before_skip", None)
+        if state is not None:
+            torch.set_rng_state(state)
+        return self._validate(val, epoch, d, batch_size)
+
     def _validate(self, val, epoch, d, batch_size):
         """Per-epoch validation through forward_supervised_AdamW in 'train' mode (adil.py:199-205).
         `val` is a ResidentImages (or None)."""
@@ -226,10 +243,12 @@ class ADIL(Attack):
             if validated:
                 val_fool = self._validate(val_res, iteration, learner.d, batch_size)
                 print(float(val_fool))
+            else:
+                self._skip_validation(val_res, batch_size)
             if iteration > 1 and abs(loss_all[iteration] - loss_all[iteration - 1]) < 1e-6:    # adil.py:207
                 break
         if loss_all and not validated:                                   # the stored value is the last epoch's
-            val_fool = self._validate(val_res, len(loss_all) - 1, learner.d, batch_size)
+            val_fool = self._final_validation(val_res, len(loss_all) - 1, learner.d, batch_size)
         self._save(learner.d, learner.v, loss_all, fooling_rate_all, val_fool)
         return learner
 
@@ -268,10 +287,12 @@ class ADIL(Attack):
             validated = self._val_due(iteration)
             if validated:
                 val_fool = self._validate(val_res, iteration, learner.d, batch_size)
+            else:
+                self._skip_validation(val_res, batch_size)
             if iteration > 1 and abs(loss_all[iteration] - loss_all[iteration - 1]) < 1e-6:    # adil.py:329
                 break
         if loss_all and not validated:
-            val_fool = self._validate(val_res, len(loss_all) - 1, learner.d, batch_size)
+            val_fool = self._final_validation(val_res, len(loss_all) - 1, learner.d, batch_size)
         self._save(learner.d, learner.v, loss_all, fooling_rate_all, val_fool)
         return learner
 

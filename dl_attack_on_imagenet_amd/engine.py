@@ -177,27 +177,38 @@ class DictionaryLearner:
         self._pending = None                     # handle of the step's all-reduce between forward_backward and update_d
 
     # -- pieces ------------------------------------------------------------- #
-    def forward_backward(self, model, x: Tensor, index: Tensor, labels: Tensor, want_d: bool, want_v: bool):
+    def synthesize(self, x: Tensor, index: Tensor, want_d: bool = True, want_v: bool = True):
+        """K1: x + D v[index] (adil.py:25-26).  Returns (xt, codes) with `codes` what backward() needs: the gather of
+        the batch's code rows also records their batch slots in `pos` (consumed + reset by update_v) and, for a D-step,
+        writes the transposed copy in the stream dtype that the grad_d contraction reads."""
         b = x.shape[0]
-        if b == 0:
-            return self._empty_batch(x, want_d)
-        # the gather of the batch's code rows also records their batch slots in `pos` (consumed + reset by update_v) and,
-        # for a D-step, writes the transposed copy in the stream dtype that the grad_d contraction reads
         vp = ops.pack_codes(self.v, index, b, pos=self.pos if want_v else None, transposed=x.dtype if want_d else None)
         vpt = None
         if want_d:
             vp, vpt = vp
-        xt = ops.synth(_flat_images(x), self.d, vp, b, fp8_absmax=self.fp8_absmax)      # K1
-        out, ls, g = input_gradient(model, xt, labels, self.loss, self.coeff, self.kappa, "sum")
-        fooled = (out.argmax(dim=-1) != labels).sum()                                    # adil.py:177
-        # K2 + K3, one pass over g; grad_v stays in the kernel's per-workgroup partial sums, which update_v sums itself
+        xt = ops.synth(_flat_images(x), self.d, vp, b, fp8_absmax=self.fp8_absmax)
+        return xt, (vp, vpt, b)
+
+    def backward(self, g: Tensor, codes, want_d: bool = True, want_v: bool = True):
+        """K2 + K3 for the upstream gradient g = dLoss/d(x + D v): one pass over g (adil.py:185 through the tensordot).
+        grad_v stays in the kernel's per-workgroup partial sums, which update_v sums itself; with a reducer the step's ONE
+        collective is started here and waited for in update_d: the update of the code rows, which does not depend on the
+        reduced gradient, runs while RCCL moves grad_d over xGMI on its own stream."""
+        vp, vpt, b = codes
         gd, gvb = ops.grad(g, self.d, vp, b, want_d=want_d, want_v=want_v, grad_d=self.grad_d if want_d else None,
                            vpt=vpt, defer_v=True)
         self._pending = None
         if want_d and self.reducer is not None:
-            # the ONE collective per step, started here and waited for in update_d: the update of the code rows, which
-            # does not depend on the reduced gradient, runs while RCCL moves grad_d over xGMI on its own stream
             self._pending = self.reducer.all_reduce_start(gd)
+        return gd, gvb
+
+    def forward_backward(self, model, x: Tensor, index: Tensor, labels: Tensor, want_d: bool, want_v: bool):
+        if x.shape[0] == 0:
+            return self._empty_batch(x, want_d)
+        xt, codes = self.synthesize(x, index, want_d, want_v)                            # K1
+        out, ls, g = input_gradient(model, xt, labels, self.loss, self.coeff, self.kappa, "sum")
+        fooled = (out.argmax(dim=-1) != labels).sum()                                    # adil.py:177
+        gd, gvb = self.backward(g, codes, want_d, want_v)                                # K2 + K3
         return ls, fooled, gd, gvb
 
     def _empty_batch(self, x: Tensor, want_d: bool):
@@ -441,10 +452,12 @@ class DDragueSolver:
         self._dyn_ring = ops.PinnedRing((3, 2), torch.float32)   # slots guarded by events: safe however far the host runs ahead
         t_sched, t_stop, iters = self.sched.t, self.stop.t, self.iters
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for j in range(3):
-                self.iterate(dyn=self._dyn[j])
-        self.sched.t, self.stop.t, self.iters = t_sched, t_stop, iters
+        try:
+            with torch.cuda.graph(graph):
+                for j in range(3):
+                    self.iterate(dyn=self._dyn[j])
+        finally:                                                 # recorded or failed: nothing was executed
+            self.sched.t, self.stop.t, self.iters = t_sched, t_stop, iters
         self._graph = graph
 
     def _replay(self) -> None:
@@ -465,8 +478,16 @@ class DDragueSolver:
                 self.iterate()
                 it += 1
             if self._graph is None:
-                self._capture()
-            while it + 3 <= steps and not self.stop.converged():
+                try:
+                    self._capture()
+                except RuntimeError as e:
+                    # a classifier whose forward / backward cannot be recorded (a library workspace allocation or an implicit
+                    # synchronisation under capture): the attack still runs, eagerly (main.py defaults to --graph 1)
+                    import warnings
+                    warnings.warn(f"hipGraph capture of the DDrague iterations failed ({str(e).splitlines()[0]}); "
+                                  "running the eager loop instead", RuntimeWarning)
+                    self._graph = False
+            while self._graph and it + 3 <= steps and not self.stop.converged():
                 self._replay()
                 it += 3
         while it < steps:

@@ -245,14 +245,26 @@ def learn_step_a(model, x: Tensor, index: Tensor, d: Tensor, v: Tensor, opt_d: A
     xt = synth(x, d, v[index])                                            # adil.py:176 -> :25-26
     out, ls, g = _input_grad(model, xt, label, loss, coeff, kappa, "sum")  # adil.py:179-185
     fooled = int((out.argmax(dim=-1) != label).sum())                     # adil.py:177
-    gd, gv_rows = grad_dv(g, d, v[index])
+    apply_gradient_a(g, index, d, v, opt_d, opt_v, eps)
+    return float(ls), fooled
+
+
+def apply_gradient_a(g: Tensor, index: Tensor, d: Tensor, v: Tensor, opt_d: AdamWState, opt_v: AdamWState, eps: float,
+                     d_operand: Optional[Tensor] = None, v_operand: Optional[Tensor] = None) -> None:
+    """The update half of learn_step_a for a GIVEN upstream gradient g = dLoss/d(x + Dv) (adil.py:185-188): backward
+    through the tensordot, AdamW on (d, ALL rows of v), l1-ball projection, clamp.  The parity tests hand the same g to
+    this function and to the HIP kernels, which takes the classifier — and its run-to-run noise — out of the comparison.
+    d_operand / v_operand: the contraction operands as the bf16-stream kernels see them (D and the batch's code rows
+    rounded to bf16); default = the fp32 masters."""
+    dop = d if d_operand is None else d_operand
+    vop = v[index] if v_operand is None else v_operand
+    gd, gv_rows = grad_dv(g, dop, vop)
     gv = torch.zeros_like(v)
     gv[index] = gv_rows                                                   # dense grad, zero rows elsewhere
     opt_d.step(d, gd)                                                     # adil.py:186 (one optimiser, 2 params)
     opt_v.step(v, gv)
     v.copy_(project_onto_l1_ball(v, eps))                                 # adil.py:187 -> :29-31
     d.clamp_(min=-1, max=1)                                               # adil.py:188 -> :33-35
-    return float(ls), fooled
 
 
 def learn_dictionary_a(model, images: Tensor, d0: Tensor, v0: Tensor, epochs_batches: Sequence[Sequence[Sequence[int]]],

@@ -1,0 +1,71 @@
+"""A synthetic workload with CLASS STRUCTURE for the ASR-parity tests (VERDICT r2 next #1c).
+
+On seeded U[0,1) images a random-init classifier's logit margins are of the size of bf16 rounding, so a bf16 and an fp32
+copy of the same network disagree about labels and fooling counts for reasons that have nothing to do with the attack
+kernels.  Here the images are noisy copies of a few coarse colour patterns and the classifier's last layer is FITTED
+to them (nearest class centroid in the frozen random backbone's standardised feature space — a closed form, seeded, a
+few seconds), so clean margins are large against bf16 rounding while the deep random backbone stays as sensitive to
+input perturbations as before: the attack has real work to do and its success rate is a stable aggregate."""
+import os
+
+import torch
+import torch.nn.functional as F
+
+
+def structured_images(n, classes=10, seed=0, size=224, noise=0.10, cells=7):
+    """(images (n,3,size,size) in [0,1], labels (n,)): class c = a coarse cells x cells colour pattern, bilinearly
+    upsampled, plus per-pixel Gaussian noise."""
+    g = torch.Generator().manual_seed(seed)
+    protos = torch.rand(classes, 3, cells, cells, generator=g)
+    protos = F.interpolate(protos, size=(size, size), mode="bilinear", align_corners=False) * 0.6 + 0.2
+    labels = torch.arange(n) % classes
+    images = (protos[labels] + noise * torch.randn(n, 3, size, size, generator=g)).clamp_(0.0, 1.0)
+    return images, labels
+
+
+@torch.no_grad()
+def fit_centroid_head(model, images, labels, classes, device, target_margin=10.0, chunk=64):
+    """Overwrite the last linear layer of `model` (Sequential(Normalize, net) from zoo.build_classifier, fp32, plain
+    modules) with the nearest-centroid classifier of its own penultimate features on (images, labels):
+    logit_c = s * (z . m_c - |m_c|^2 / 2), z = standardised feature, m_c = class mean; s scales the median clean
+    margin to `target_margin`.  The other output classes get weight 0 and a large negative bias.  Returns the clean
+    logit margins of the fitted network on the images."""
+    net = model[-1]
+    fc = net.fc if hasattr(net, "fc") else net.classifier
+    feats = []
+    hook = fc.register_forward_pre_hook(lambda m, a: feats.append(a[0].detach().double().cpu()))
+    for part in images.split(chunk):
+        model(part.to(device))
+    hook.remove()
+    f = torch.cat(feats)
+    mu, sd = f.mean(0), f.std(0) + 1e-6 * f.std(0).max()
+    z = (f - mu) / sd
+    means = torch.stack([z[labels == c].mean(0) for c in range(classes)])           # (C, F)
+    logits = z @ means.t() - 0.5 * (means * means).sum(1)
+    top2 = logits.topk(2, dim=1).values
+    s = target_margin / float((top2[:, 0] - top2[:, 1]).median())
+    w = s * means / sd                                                                # (C, F) on raw features
+    b = s * (-(means * (mu / sd)).sum(1) - 0.5 * (means * means).sum(1))
+    fc.weight.zero_()
+    fc.bias.fill_(-1.0e4)
+    fc.weight[:classes] = w.to(fc.weight)
+    fc.bias[:classes] = b.to(fc.bias)
+    out = torch.cat([model(part.to(device)).double().cpu() for part in images.split(chunk)])
+    top2 = out.topk(2, dim=1).values
+    return top2[:, 0] - top2[:, 1], out.argmax(1)
+
+
+def fitted_classifiers(name, images, labels, classes, device, tmp_dir, seed=0):
+    """(fp32 plain network, the product's bf16 network) sharing ONE set of weights incl. the fitted head: the fp32
+    network is fitted, its state_dict saved, and both are rebuilt from that file through zoo.build_classifier(weights=)
+    — the same route a torchvision checkpoint takes."""
+    from dl_attack_on_imagenet_amd import zoo
+    ref = zoo.build_classifier(name, seed=seed, device=device)
+    margins, pred = fit_centroid_head(ref, images, labels, classes, device)
+    path = os.path.join(str(tmp_dir), f"{name}_fitted.pt")
+    torch.save(ref[-1].state_dict(), path)
+    fused = zoo.canonical_name(name).startswith("resnet")
+    fast = zoo.build_classifier(name, seed=seed, weights=path, device=device, dtype=torch.bfloat16, channels_last=fused,
+                                fuse_bn_act=fused, fuse_stem=fused)
+    ref = zoo.build_classifier(name, seed=seed, weights=path, device=device)
+    return ref, fast, margins, pred

@@ -819,3 +819,25 @@ def test_val_every_writes_the_same_dictionary_file(tmp_path):
         assert torch.equal(d, files[0][0]) and torch.equal(v, files[0][1]) and loss_all == files[0][2] and fool == files[0][3]
         assert float(val_fool) == float(files[0][4]) == float(z["logits_val_fool"])
     assert counts[1] < counts[2] < counts[0]
+
+
+def test_val_every_keeps_the_seeded_shuffle_stream(tmp_path):
+    """on the DEFAULT path (shuffled loaders, no injected batch order) a skipped validation still consumes the
+    validation loader's draws from the global torch RNG, so a seeded run writes the same D, V, losses and stored
+    validation value for val_every = 1, 2 and 0 (the end-of-run validation replays the skipped epoch's shuffle)."""
+    from attacks import ADIL
+    from tinynet import make_tinynet
+    net = make_tinynet(5).to(DEV)
+    g = torch.Generator().manual_seed(41)
+    images, val = torch.rand(21, 3, 32, 32, generator=g), torch.rand(10, 3, 32, 32, generator=g)
+    d0, v0 = -1 + 2 * torch.rand(3, 32, 32, 4, generator=g), torch.rand(21, 4, generator=g)
+    files = []
+    for every in (1, 2, 0):
+        torch.manual_seed(2024)
+        atk = ADIL(net, eps=0.3, steps=3, n_atoms=4, batch_size=6, data_train=IndexedTensorDataset(images),
+                   data_val=IndexedTensorDataset(val), model_name=f"seeded{every}", loss="ce", init_d=d0, init_v=v0,
+                   dict_dir=str(tmp_path), val_every=every)
+        files.append(torch.load(atk.model_file, map_location="cpu"))
+    for d, v, loss_all, fool, val_fool in files[1:]:
+        assert torch.equal(d, files[0][0]) and torch.equal(v, files[0][1]) and loss_all == files[0][2] and fool == files[0][3]
+        assert float(val_fool) == float(files[0][4])
