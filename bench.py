@@ -29,15 +29,20 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, ch
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=100)
-    p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--mode", default="learn", choices=["learn", "inference"],
+    p.add_argument("--steps", type=int, default=None, help="timed steps (default: 100; --mode transfer: 4 batches)")
+    p.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 5; --mode transfer: 1 batch)")
+    p.add_argument("--mode", default="learn", choices=["learn", "inference", "transfer"],
                    help="learn: one step = the loop body of learn_dictionary_a (the headline, configs[1]); inference: one "
-                        "step = one iteration of forward_supervised_DDrague over the batch (the attack(x, y) path that "
-                        "transfer evaluation, configs[3], runs)")
+                        "step = one iteration of forward_supervised_DDrague over the batch; transfer: configs[3] as the "
+                        "workload it is — one step = one batch through performance.get_transfer_performance: the full "
+                        "attack(x, y) (--steps-inference DDrague iterations with the stop test) against --model, then the six "
+                        "classifiers of the reference CLI scored on the adversary")
     p.add_argument("--model", default="resnet50")
     p.add_argument("--batch", type=int, default=512, help="images per GPU (weak scaling)")
-    p.add_argument("--atoms", type=int, default=50)
+    p.add_argument("--atoms", type=int, default=None, help="dictionary atoms (default 50 = configs[1]; --mode transfer: 100, the "
+                                                           "reference's n_atoms, demo_dL_attack.py:88,114)")
+    p.add_argument("--steps-inference", type=int, default=100, help="--mode transfer: DDrague iterations per attack call "
+                                                                    "(demo_dL_attack.py:186 default)")
     p.add_argument("--image-size", type=int, default=224)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--loss", default="logits", choices=["logits", "ce"])
@@ -61,7 +66,12 @@ def parse_args():
     p.add_argument("--cpu-steps", type=int, default=1)
     p.add_argument("--cpu-config1", type=int, default=1, help="also run configs[0] (resnet18, 32 images, 10 atoms, 20 "
                                                               "iterations, fp32) in full on the host cores and on the GPU")
-    return p.parse_args()
+    a = p.parse_args()
+    transfer = a.mode == "transfer"
+    a.steps = a.steps if a.steps is not None else (4 if transfer else 100)
+    a.warmup = a.warmup if a.warmup is not None else (1 if transfer else 5)
+    a.atoms = a.atoms if a.atoms is not None else (100 if transfer else 50)
+    return a
 
 
 class KernelTimer:
@@ -239,6 +249,156 @@ def cpu_baseline(args, P_shape, dev):
     return out
 
 
+TRANSFER_TARGETS = ("resnet18", "densenet121", "googlenet", "inception_v3", "mobilenet_v2", "vgg11")   # demo_dL_attack.py:41-53
+
+
+class _SeededImages(torch.utils.data.Dataset):
+    """n seeded U[0,1) images (3,S,S), generated item by item (nothing of size n*P is ever held on the host)."""
+
+    def __init__(self, n, size, seed):
+        self.n, self.size, self.seed = n, size, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return torch.rand(3, self.size, self.size, generator=torch.Generator().manual_seed(self.seed * 1_000_003 + i)), 0
+
+
+def cpu_baseline_transfer(args, shape, b=4):
+    """oracle.transfer_performance (performance.py:205-232 restated) on the host cores: b images of the bench workload,
+    the same six target architectures (fp32, CPU), the attack = the oracle's forward_supervised_ddrague against the
+    source architecture.  100 DDrague iterations on the CPU would take minutes, so the attack is timed at 1 and at 3
+    iterations, which gives the per-iteration cost and the per-call fixed cost (labels, Gram / pseudo-inverse, final
+    synthesis); the rate reported is b / (fixed + steps_inference * per_iteration + scoring) — stated in `sample`."""
+    from oracle import adil_oracle as O
+    from dl_attack_on_imagenet_amd import zoo
+    threads = torch.get_num_threads()
+    k, eps = args.atoms, 8 / 255
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(b, *shape, generator=g)
+    d = -1 + 2 * torch.rand(*shape, k, generator=g)
+    src = zoo.build_classifier(args.model, seed=0)
+    targets = {name: zoo.build_classifier(name, seed=1 + i) for i, name in enumerate(TRANSFER_TARGETS)}
+    O.forward_supervised_ddrague(src, x[:1], d, eps, 1, args.loss)                       # warm-up (allocators, MKL)
+    t = {}
+    for iters in (1, 3):
+        t0 = time.perf_counter()
+        adv = O.forward_supervised_ddrague(src, x, d, eps, iters, args.loss)
+        t[iters] = time.perf_counter() - t0
+    per_iter = (t[3] - t[1]) / 2
+    fixed = max(t[1] - per_iter, 0.0)
+    t0 = time.perf_counter()
+    perf = O.transfer_performance(lambda xx, yy: adv, targets, [(x, torch.zeros(b, dtype=torch.long))], b)
+    score = time.perf_counter() - t0
+    full = fixed + args.steps_inference * per_iter + score
+    return {"value": b / full, "unit": "attacked images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle.transfer_performance on {b} of the bench's images, fp32, torch {torch.__version__} CPU, {threads} "
+                      f"threads of {os.cpu_count()} logical cores: attack timed at 1 and 3 DDrague iterations ({t[1]:.1f} s, "
+                      f"{t[3]:.1f} s -> {per_iter:.2f} s per iteration, {fixed:.2f} s fixed per call), scoring on the six "
+                      f"targets {score:.1f} s; value = {b} / (fixed + {args.steps_inference} * per_iteration + scoring) = "
+                      f"{b} / {full:.0f} s (extrapolated, not run in full)",
+            "fooling_rates_of_the_3_iteration_adversary": {n: perf[n]["fooling_rate"] for n in perf}}
+
+
+def bench_transfer(args, rank, world, dev, timer):
+    """configs[3]: performance.get_transfer_performance (performance.py:183-232) over an evaluation set resident in HBM."""
+    import tempfile
+    import performance as perf
+    from attacks import ADIL
+    from dl_attack_on_imagenet_amd import dist as adist, loader, zoo
+    sdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    s_bytes = 2 if args.dtype == "bf16" else 4
+    B, K, S = args.batch, args.atoms, args.image_size
+    shape, P, eps = (3, S, S), 3 * S * S, 8 / 255
+    fused = bool(args.fuse_bn_act) and zoo.canonical_name(args.model).startswith("resnet")
+    source = zoo.build_classifier(args.model, seed=0, device=dev, dtype=sdtype, channels_last=bool(args.channels_last) and fused,
+                                  fuse_bn_act=fused, fuse_stem=bool(args.fuse_stem and fused and args.dtype == "bf16"))
+    targets = {name: zoo.build_classifier(name, seed=1 + i, device=dev, dtype=sdtype) for i, name in enumerate(TRANSFER_TARGETS)}
+    tmp = tempfile.mkdtemp(prefix=f"adil_bench_rank{rank}_")
+    gd0 = torch.Generator().manual_seed(7)                           # the same dictionary on every rank (one learned D, replicated)
+    torch.save([-1 + 2 * torch.rand(*shape, K, generator=gd0), torch.zeros(1), [], [], torch.tensor(0.)],
+               os.path.join(tmp, "ImageNet_bench.bin"))
+    atk = ADIL(source, eps=eps, n_atoms=K, attack="supervised", model_name="bench", loss=args.loss, kappa=50,
+               steps_inference=args.steps_inference, dict_dir=tmp, stream_dtype=sdtype)
+
+    def loader_of(batches, seed):
+        # performance.py hands batch i to rank i % world: a set of world * batches batches, of which this rank uploads
+        # and keeps its own `batches` (weak scaling: every rank attacks `batches` batches of B images)
+        n = world * batches * B
+        return loader.ResidentBatches(_SeededImages(n, S, seed), torch.zeros(n, dtype=torch.long), B, dev, sdtype,
+                                      shard=(rank, world))
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    warm = loader_of(max(args.warmup, 0), 1000) if args.warmup > 0 else None
+    timed = loader_of(args.steps, 2000)
+    if warm is not None:
+        perf.get_transfer_performance({"adil": [atk]}, targets, warm, device=dev)
+    sync()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    result = perf.get_transfer_performance({"adil": [atk]}, targets, timed, device=dev)["adil"]
+    sync()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        elapsed = float(adist.all_reduce_(torch.tensor([elapsed], dtype=torch.float64, device=dev), torch.distributed.ReduceOp.MAX))
+    kern_ms = timer.summary_ms()
+    launches = {k: len(v) for k, v in timer.records.items()}
+    alg = algorithmic_bytes(B, P, K, B, s_bytes, "inference")
+    dom = max((k for k in kern_ms if k in alg), key=lambda k: kern_ms[k] * launches[k])
+    achieved = alg[dom] / (kern_ms[dom] * 1e-3) / 1e9
+    iters_run = launches.get("zstep_", 0) / max(args.steps, 1)
+    out = {
+        "metric": "attacked images/sec (transfer evaluation: full attack(x, y) + six targets scored, classifiers included)",
+        "value": world * B * args.steps / elapsed, "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": (f"performance.get_transfer_performance (BASELINE.json configs[3]): one learned-dictionary attack "
+                                f"(ADiL forward_supervised_DDrague, {args.steps_inference} iterations with the stop test, {K} atoms, "
+                                f"loss={args.loss}) against {args.model}, adversary scored on {len(targets)} targets "
+                                f"({', '.join(targets)}), {B} images per batch, {args.steps} batches per GPU, {S}x{S}, {args.dtype} "
+                                f"image streams, fp32 z + AdamW moments; evaluation set resident in HBM (loader.ResidentBatches)"),
+                   "classifier": f"random-init {args.model} (source{', FusedResNet' if fused else ''}) and six random-init targets, frozen, eval",
+                   "global_batch": world * B, "atoms": K, "steps_inference": args.steps_inference,
+                   "ddrague_iterations_run_per_batch": iters_run,
+                   "parallelism": f"dp{world}: batches dealt to ranks (performance.py path), D replicated, final sums all-reduced",
+                   "collective": {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                                  "world_size": world, adist.IPC_ENV: os.environ.get(adist.IPC_ENV)},
+                   "transfer_fooling_rates": {n: result[n]["fooling_rate"] for n in result},
+                   "rmse": next(iter(result.values()))["rmse"]},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, K),
+                     "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern_ms[dom], "launches_timed": launches[dom],
+                     "empty_event_bracket_ms": timer.empty_bracket_ms()},
+        "kernels_ms_per_launch": kern_ms, "kernel_launches_timed": launches,
+        "dictionary_path_ms_per_step": sum(kern_ms[k] * launches[k] for k in kern_ms) / args.steps,
+    }
+    if rank == 0 and world == 1 and args.cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_transfer(args, shape)
+    return out
+
+
+def measured_traffic(group, atoms):
+    """HBM bytes per launch of a launch group from the PMC passes (profiles/hbm_traffic.json, written by tools/pmc_traffic.py
+    from two separate rocprofv3 --pmc runs): only when the file was collected from THIS build of the kernels (it records
+    the hash of csrc/ + include/ it was measured on) and at this atom count; otherwise null."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        from dl_attack_on_imagenet_amd.build import source_hash
+        rec = json.load(open(tpath))
+        if rec.get("_source", {}).get("kernel_source_hash") != source_hash() or rec.get("_source", {}).get("atoms", 50) != atoms:
+            return None
+        return rec.get(group)
+    except Exception:
+        return None
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves.  This parent has
     made no GPU call (importing torch does not initialise HIP) and never will: the ranks are fresh child processes
@@ -271,6 +431,14 @@ def main():
 
     from dl_attack_on_imagenet_amd import engine, ops, zoo
     timer = KernelTimer(ops)
+    if args.mode == "transfer":
+        out = bench_transfer(args, rank, world, dev, timer)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if torch.distributed.is_initialized():
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     sdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     s_bytes = 2 if args.dtype == "bf16" else 4
     B, K, S = args.batch, args.atoms, args.image_size
@@ -362,13 +530,7 @@ def main():
     alg = algorithmic_bytes(B, P, K, B, s_bytes, args.mode)
     dom = max((k for k in kern_ms if k in alg), key=lambda k: kern_ms[k])
     achieved = alg[dom] / (kern_ms[dom] * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")      # filled from a separate rocprofv3 --pmc run
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(dom)
-        except Exception:
-            traffic = None
+    traffic = measured_traffic(dom, K)                              # from separate rocprofv3 --pmc runs of THIS build, else null
     dict_ms = sum(kern_ms.values())
     out = {
         "metric": "adversarial images/sec (ADiL learning step, classifier included)" if args.mode == "learn" else

@@ -21,6 +21,17 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources and headers: identifies the build a measurement was taken on
+    (profiles/hbm_traffic.json records it; bench.py reports `roofline.traffic` only for a matching build)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(LIBPATH):
         return True

@@ -104,3 +104,43 @@ class ResidentImages:
         for idx in order:
             index = torch.as_tensor([int(i) for i in idx], dtype=torch.int64).to(self.images.device, non_blocking=True)
             yield index, ops.gather_images(self.images, index)
+
+
+class ResidentBatches:
+    """A DataLoader-like view of an evaluation set that is resident in HBM: iterating yields (x, y) DEVICE batches in
+    order, each x formed by one gather kernel — what performance.performance / get_transfer_performance_aux consume
+    (they use `for x, y in data`, `data.batch_size` and `len(data.dataset)`, performance.py:156-160, :207-213).
+    Replaces the host DataLoader of the reference's evaluation (demo_dL_attack.py:81-86: per-item fetch, stack and a
+    PCIe copy per batch, every pass again): every image crosses PCIe once, when the set is built.
+
+    Data-parallel evaluation (one process per GPU): performance.py gives batch i to rank i % world, so with
+    `shard=(rank, world)` only THIS rank's batches are uploaded and kept (50 000 images over 8 GPUs: 6 250 each); the
+    batches of the other ranks are yielded as (None, None) placeholders, which the consumer skips without looking."""
+
+    def __init__(self, dataset, labels: Tensor, batch_size: int, device, dtype: torch.dtype = torch.float32,
+                 shard: Tuple[int, int] = (0, 1)):
+        n, bs = len(dataset), int(batch_size)
+        if labels.shape[0] != n:
+            raise ValueError("ResidentBatches: one label per image")
+        self.batch_size, self.shard = bs, (int(shard[0]), int(shard[1]))
+        self.dataset = range(n)                                  # only its length is used (performance.py:207)
+        rank, world = self.shard
+        self._bounds = [(lo, min(lo + bs, n)) for lo in range(0, n, bs)]
+        owned = [r for i, (lo, hi) in enumerate(self._bounds) if i % world == rank for r in range(lo, hi)]
+        self.images = ResidentImages(dataset, device, dtype, rows=owned)
+        self.labels = labels[torch.as_tensor(owned, dtype=torch.int64)].to(device=self.images.device, dtype=torch.int64) \
+            if owned else torch.zeros(0, dtype=torch.int64, device=self.images.device)
+
+    def __len__(self) -> int:
+        return len(self._bounds)
+
+    def __iter__(self) -> Iterator[Tuple[Optional[Tensor], Optional[Tensor]]]:
+        rank, world = self.shard
+        at = 0
+        for i, (lo, hi) in enumerate(self._bounds):
+            if i % world != rank:
+                yield None, None
+                continue
+            index = torch.arange(at, at + hi - lo, device=self.images.device)
+            at += hi - lo
+            yield self.images.gather(index), self.labels[index]

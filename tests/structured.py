@@ -55,13 +55,13 @@ def fit_centroid_head(model, images, labels, classes, device, target_margin=10.0
     return top2[:, 0] - top2[:, 1], out.argmax(1)
 
 
-def fitted_classifiers(name, images, labels, classes, device, tmp_dir, seed=0):
+def fitted_classifiers(name, images, labels, classes, device, tmp_dir, seed=0, target_margin=10.0):
     """(fp32 plain network, the product's bf16 network) sharing ONE set of weights incl. the fitted head: the fp32
     network is fitted, its state_dict saved, and both are rebuilt from that file through zoo.build_classifier(weights=)
     — the same route a torchvision checkpoint takes."""
     from dl_attack_on_imagenet_amd import zoo
     ref = zoo.build_classifier(name, seed=seed, device=device)
-    margins, pred = fit_centroid_head(ref, images, labels, classes, device)
+    margins, pred = fit_centroid_head(ref, images, labels, classes, device, target_margin=target_margin)
     path = os.path.join(str(tmp_dir), f"{name}_fitted.pt")
     torch.save(ref[-1].state_dict(), path)
     fused = zoo.canonical_name(name).startswith("resnet")

@@ -384,7 +384,10 @@ def _two_rank_learner_run(tmp_path, env_extra):
     sp = torch.load(tmp_path / "dicts" / "ImageNet_sp.bin", map_location="cpu")
     assert torch.equal(dp[0], d_ranks[0])
     # the two ranks sum their partial grad_d in a different order than one pass over the global batch: fp32 rounding only
-    assert float((dp[0] - sp[0]).abs().max()) <= 2e-5 and float((dp[1] - sp[1]).abs().max()) <= 2e-5
+    # (median: rounding; maximum: an entry whose gradient is ~1e-8 sits in AdamW's eps regime, where a 1e-10 difference of
+    # its first moment moves it by lr * 1e-10 / 1e-8)
+    dd, dv = (dp[0] - sp[0]).abs(), (dp[1] - sp[1]).abs()
+    assert float(dd.median()) <= 1e-6 and float(dd.max()) <= 5e-4 and float(dv.median()) <= 1e-6 and float(dv.max()) <= 5e-4
     assert dp[1].shape == sp[1].shape and list(dp[3]) == list(sp[3])     # V gathered from both ranks; fooling rates per epoch
     assert max(abs(a - b) for a, b in zip(dp[2], sp[2])) <= 1e-4 * max(1.0, max(abs(a) for a in sp[2]))
     assert abs(float(dp[4]) - float(sp[4])) < 1e-6                        # sharded validation (global stop test)
@@ -841,3 +844,60 @@ def test_val_every_keeps_the_seeded_shuffle_stream(tmp_path):
     for d, v, loss_all, fool, val_fool in files[1:]:
         assert torch.equal(d, files[0][0]) and torch.equal(v, files[0][1]) and loss_all == files[0][2] and fool == files[0][3]
         assert float(val_fool) == float(files[0][4])
+
+
+def test_resident_batches_feed_the_evaluation_harness(tmp_path):
+    """loader.ResidentBatches (the evaluation set resident in HBM, one gather kernel per batch) is a drop-in for the host
+    DataLoader in performance.get_transfer_performance: same numbers on the G15 fixture; with shard=(rank, world) a rank
+    uploads and yields only the batches performance.py deals to it (batch i -> rank i % world), placeholders elsewhere."""
+    import performance as perf
+    from attacks import ADIL
+    from dl_attack_on_imagenet_amd import loader
+    z = load_golden("g15_transfer")
+    targets = {name: tinynet_from_npz(z, prefix=f"{name}.").to(DEV) for name in ("src", "t1", "t2")}
+    torch.save([t(z["d"]), torch.zeros(1), [], [], torch.tensor(0.)], os.path.join(tmp_path, "ImageNet_g15.bin"))
+    atk = ADIL(targets["src"], eps=float(z["eps"]), n_atoms=z["d"].shape[-1], attack="supervised", model_name="g15", loss="logits",
+               steps_inference=int(z["steps"]), kappa=float(z["kappa"]), dict_dir=str(tmp_path))
+    images, labels, bs = t(z["images"]), t(z["labels"]), int(z["batch_size"])
+    ds = torch.utils.data.TensorDataset(images, labels)
+    host = perf.get_transfer_performance({"adil": [atk]}, targets, torch.utils.data.DataLoader(ds, batch_size=bs), device=torch.device(DEV))
+    res = loader.ResidentBatches(ds, labels, bs, DEV)
+    assert len(res) == (len(ds) + bs - 1) // bs and len(res.dataset) == len(ds) and res.batch_size == bs
+    resident = perf.get_transfer_performance({"adil": [atk]}, targets, res, device=torch.device(DEV))
+    for name in targets:
+        for key in ("fooling_rate", "rmse", "mse"):
+            assert host["adil"][name][key] == resident["adil"][name][key], (name, key)
+        assert abs(resident["adil"][name]["fooling_rate"] - float(z[f"{name}_fooling_rate"])) < 1e-9
+    n = len(ds)
+    for world in (2, 3):
+        seen = []
+        for rank in range(world):
+            part = loader.ResidentBatches(ds, labels, bs, DEV, shard=(rank, world))
+            got = list(part)
+            assert len(got) == len(res)
+            for i, (x, y) in enumerate(got):
+                if i % world != rank:
+                    assert x is None and y is None
+                else:
+                    lo, hi = i * bs, min((i + 1) * bs, n)
+                    assert torch.equal(x.cpu(), images[lo:hi]) and torch.equal(y.cpu(), labels[lo:hi])
+                    seen += list(range(lo, hi))
+            assert len(part.images) == sum(min((i + 1) * bs, n) - i * bs for i in range(len(res)) if i % world == rank)
+        assert sorted(seen) == list(range(n))
+
+
+def test_bench_transfer_mode_line(tmp_path):
+    """`bench.py --mode transfer` (configs[3] as a workload) at a plumbing size: one JSON line with the contract's keys, the
+    six targets of the reference CLI scored, the z-step as the roofline kernel, the DDrague iteration count per batch."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "transfer", "--model", "resnet18", "--batch", "4",
+                        "--atoms", "10", "--steps", "2", "--warmup", "1", "--steps-inference", "5", "--cpu-baseline", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["unit"] == "images/sec" and line["value"] > 0
+    assert set(line["config"]["transfer_fooling_rates"]) == {"resnet18", "densenet121", "googlenet", "inception_v3", "mobilenet_v2", "vgg11"}
+    assert line["roofline"]["kernel"] == "zstep_" and line["roofline"]["launches_timed"] == 2 * 5
+    assert line["config"]["ddrague_iterations_run_per_batch"] == 5
