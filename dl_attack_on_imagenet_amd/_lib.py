@@ -33,6 +33,7 @@ SIGNATURES = {
     "adil_adamw_l1ball": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
                                   c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                   c_void_p, c_int, c_int, c_void_p]),
+    "adil_atom_l1ball_project": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "adil_l1ball_project": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     "adil_l2ball_project": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     "adil_ista_step": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p]),

@@ -24,14 +24,14 @@ def project_onto_l1_ball(x, eps):
 
 
 def constraint_dict(d, constr_set='l2ball'):
-    """Per-atom constraint on D (C,H,W,K), IN PLACE like the reference, and returned (utils.py:44-57)."""
-    if constr_set not in ('l2ball', 'l2sphere'):
-        raise NotImplementedError("constraint_dict: only 'l2ball' and 'l2sphere' are on the ADiL hot path")
-    if d.is_contiguous():
-        ops.atom_l2_project_(d, sphere=(constr_set == 'l2sphere'))
-    else:
-        tmp = d.contiguous()
+    """Per-atom constraint on D (C,H,W,K), IN PLACE like the reference, and returned (utils.py:44-57): 'l2sphere',
+    'l2ball', anything else = the reference's else-branch, every (channel, atom) row onto the l1 ball of radius 1."""
+    tmp = d if d.is_contiguous() else d.contiguous()
+    if constr_set in ('l2ball', 'l2sphere'):
         ops.atom_l2_project_(tmp, sphere=(constr_set == 'l2sphere'))
+    else:
+        ops.atom_l1_project_(tmp, 1.0)                                        # utils.py:55-56
+    if tmp is not d:
         d.copy_(tmp)
     return d
 

@@ -370,6 +370,51 @@ __global__ __launch_bounds__(256) void atom_scale_kernel(float* __restrict__ d, 
     }
 }
 
+// ---- K11: constraint_dict's l1 branch (utils.py:55-56): every (channel, atom) row of H*W pixels onto the l1 ball ---- //
+// One workgroup per row; the row is strided in D's layout (element (c, p, k) at (c*HW + p)*K + k).  Rows are far longer
+// than the wave-sized code rows of l1ball_row, so the threshold is found without sorting (Michelot 1986): start from all
+// entries active, theta = (sum of active |x| - r) / #active, drop the entries with |x| <= theta, repeat until nothing
+// drops — at the fixed point theta is Duchi's (cumsum[rho] - r) / rho of the sort-based reference.  Sums in fp64 with a
+// fixed reduction tree (bitwise reproducible).  No caller upstream: correctness first, HBM passes second.
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    __syncthreads();                                   // red may still be read from the previous call
+    if (lane == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
+    __syncthreads();
+    a = 0.0; b = 0.0;
+    for (int i = 0; i < nw; ++i) { a += red[2 * i]; b += red[2 * i + 1]; }
+}
+
+__global__ __launch_bounds__(1024) void atom_l1ball_kernel(float* __restrict__ d, int HW, int K, float radius) {
+    __shared__ double red[32];
+    const int c = blockIdx.x / K, k = blockIdx.x - c * K;
+    float* row = d + (size_t)c * HW * K + k;
+    double l1 = 0.0, cnt = 0.0;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) { l1 += (double)fabsf(row[(size_t)p * K]); cnt += 1.0; }
+    block_sum2(l1, cnt, red);
+    if ((float)l1 < radius) return;                    // strict '<' (utils.py:33): rows inside the ball are untouched
+    double theta = (l1 - (double)radius) / cnt;
+    for (int it = 0; it < 4096; ++it) {                // terminates after at most HW rounds; a handful in practice
+        double s = 0.0, n = 0.0;
+        for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+            const double a = (double)fabsf(row[(size_t)p * K]);
+            if (a > theta) { s += a; n += 1.0; }
+        }
+        block_sum2(s, n, red);
+        if (n == cnt) break;                           // nothing dropped: theta is the threshold
+        cnt = n;
+        theta = (s - (double)radius) / n;
+    }
+    const float th = (float)theta;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+        const float x = row[(size_t)p * K];
+        const float pr = fmaxf(fabsf(x) - th, 0.0f);
+        row[(size_t)p * K] = (x > 0.0f) ? pr : ((x < 0.0f) ? -pr : 0.0f * pr);
+    }
+}
+
 // ---- K7: the Gram matrix and D * M^T are MFMA kernels in adil_contract.hip (adil_gram, adil_dict_rightmul) ---- //
 
 // ---- K12: per-image evaluation sums ----------------------------------------- //
@@ -563,6 +608,14 @@ extern "C" int adil_atom_scale(float* d, int P, int K, const float* norms, int s
     const size_t n = (size_t)P * K;
     hipLaunchKernelGGL(atom_scale_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, d, n, K, norms,
                        sphere);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_atom_l1ball_project(float* d, int C, int HW, int K, float radius, void* stream) {
+    ADIL_ENTER();
+    if (!d || C <= 0 || HW <= 0 || K <= 0 || radius < 0.0f) return ADIL_EINVAL;
+    hipLaunchKernelGGL(atom_l1ball_kernel, dim3(C * K), dim3(1024), 0, (hipStream_t)stream, d, HW, K, radius);
     ADIL_CHECK_LAUNCH();
     return 0;
 }

@@ -471,6 +471,18 @@ def atom_l2_project_(d: Tensor, sphere: bool = False, radius: float = 1.0) -> Te
     return d
 
 
+def atom_l1_project_(d: Tensor, radius: float = 1.0) -> Tensor:
+    """constraint_dict's l1 branch in place (utils.py:55-56): every (channel, atom) row of H*W pixels of the (C,H,W,K)
+    dictionary onto the l1 ball of `radius`."""
+    lib = _lib.load()
+    _dev(d, "d", torch.float32)
+    if d.dim() != 4:
+        raise ValueError("atom_l1_project_: the dictionary must be (C,H,W,K)")
+    c, h, w, k = d.shape
+    _lib.check(lib.adil_atom_l1ball_project(_ptr(d), c, h * w, k, float(radius), _stream()), "adil_atom_l1ball_project")
+    return d
+
+
 def gram(d: Tensor) -> Tensor:
     """D^T D (K x K) (adil.py:523)."""
     lib = _lib.load()

@@ -161,6 +161,11 @@ int adil_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, int reset_po
                       float* max_abs_delta, const float* skip_if_below, float skip_threshold, float* clear,
                       const float* dyn_scalars, const float* slabs, int nslabs, int slab_rows, void* stream);
 
+/* constraint_dict's third branch (utils.py:55-56: `project_onto_l1_ball(d[:, :, :, ind], eps=1)` per atom): every
+ * (channel, atom) row of HW pixels of the (C,H,W,K) dictionary onto the l1 ball of `radius`, in place.  Rows of any
+ * length (sort-free threshold search); no caller upstream. */
+int adil_atom_l1ball_project(float* d, int C, int HW, int K, float radius, void* stream);
+
 /* Row-wise Euclidean projection onto the l1 ball, in place: project_onto_l1_ball (utils.py:21-41). */
 int adil_l1ball_project(float* x, int N, int K, float radius, void* stream);
 

@@ -555,11 +555,24 @@ def g15_transfer():
     save("g15_transfer", images=images, labels=labels, d=d, eps=eps, steps=steps, kappa=50.0, batch_size=5, **nets, **out)
 
 
+def g16_constraint_l1():
+    """constraint_dict's third branch (utils.py:55-56): every (channel, atom) row of H*W pixels onto the l1 ball of
+    radius 1.  No caller upstream; pinned all the same."""
+    g = torch.Generator().manual_seed(116)
+    d = torch.randn(3, 12, 10, 5, generator=g) * 0.05          # rows of 120 pixels, l1 norm ~ 4.8: outside the ball
+    d[..., 0] *= 0.05                                           # atom 0: every row inside the ball (untouched)
+    d[1, :, :, 2] = 0.0                                         # a zero row
+    d[2, 0, :4, 3] = 0.7                                        # ties among the largest magnitudes
+    ref = U.constraint_dict(d.clone(), "l1ball")
+    close(O.constraint_dict(d, "l1ball"), ref, 1e-7)
+    save("g16_constraint_l1", d=d, l1ball=ref)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (g1_l1ball, g2_constraints, g3_softshrink, g4_synth_grad, g5_floss, g6_adamw_steps, g7_learn_a,
                g8_learn_b, g9_ddrague, g10_adamw_inference, g11_unsupervised, g12_ista_and_metrics, g13_sadil_updated,
-               g14_uappgd, g15_transfer):
+               g14_uappgd, g15_transfer, g16_constraint_l1):
         if only and fn.__name__.split("_")[0] not in only:
             continue
         print(fn.__name__)

@@ -31,7 +31,9 @@ def fit_centroid_head(model, images, labels, classes, device, target_margin=10.0
     margin to `target_margin`.  The other output classes get weight 0 and a large negative bias.  Returns the clean
     logit margins of the fitted network on the images."""
     net = model[-1]
-    fc = net.fc if hasattr(net, "fc") else net.classifier
+    fc = net.fc if hasattr(net, "fc") else (net.classifier if hasattr(net, "classifier") else net.heads.head)
+    if not isinstance(fc, torch.nn.Linear):
+        raise TypeError("fit_centroid_head: the network's last layer must be a Linear")
     feats = []
     hook = fc.register_forward_pre_hook(lambda m, a: feats.append(a[0].detach().double().cpu()))
     for part in images.split(chunk):

@@ -798,3 +798,23 @@ def test_deferred_reduction_sums_match_the_oracle_at_full_size():
     got = o.pack_codes(lazy, None, b)[:b, :k]
     ref = gup.double().flatten(1) @ d.to(torch.bfloat16).double().reshape(-1, k)
     assert float((got.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7
+
+
+def test_constraint_dict_l1_branch_golden_and_full_size():
+    """constraint_dict's else-branch (utils.py:55-56; no caller upstream): every (channel, atom) row of H*W pixels onto the
+    l1 ball of radius 1 — fixture G16 (the reference's own output) and a full-size dictionary against the oracle's
+    sort-based projection, plus the size-independent properties: row l1 norms <= 1, idempotence, untouched inside rows."""
+    from dl_attack_on_imagenet_amd.attacks import utils as U
+    z = load_golden("g16_constraint_l1")
+    d = t(z["d"], DEV).contiguous()
+    out = U.constraint_dict(d.clone(), "l1ball")
+    close(out, z["l1ball"], 2e-7, "G16")
+    g0 = torch.Generator().manual_seed(16)
+    big = torch.randn(3, 224, 224, 7, generator=g0) * 1e-4          # rows of 50176 pixels, l1 norm ~ 4
+    big[..., 0] *= 0.1                                               # atom 0 inside the ball
+    got = U.constraint_dict(big.to(DEV), "l1ball")
+    ref = O.constraint_dict(big, "l1ball")
+    close(got, ref, 2e-8, "full size")      # the oracle's fp32 cumsum over 50176 sorted values carries ~2e-9 into its threshold
+    l1 = got.abs().sum(dim=(1, 2)).cpu()
+    assert float(l1.max()) <= 1.0 + 1e-5 and torch.equal(got[..., 0].cpu(), big[..., 0])
+    close(U.constraint_dict(got.clone(), "l1ball"), got, 2e-8, "idempotent")

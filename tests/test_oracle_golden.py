@@ -204,3 +204,8 @@ def test_g15_transfer_performance():
         close(perf[name]["fooling_rate"], z[f"{name}_fooling_rate"], 1e-6)
         close(perf[name]["rmse"], z[f"{name}_rmse"], 1e-6)
         close(perf[name]["mse"], z[f"{name}_mse"], 1e-4)
+
+
+def test_g16_constraint_dict_l1_branch():
+    z = load_golden("g16_constraint_l1")
+    close(O.constraint_dict(t(z["d"]), "l1ball"), z["l1ball"], 1e-7)
