@@ -388,7 +388,7 @@ def measured_traffic(group, atoms):
     """HBM bytes per launch of a launch group from the PMC passes (profiles/hbm_traffic.json, written by tools/pmc_traffic.py
     from two separate rocprofv3 --pmc runs): only when the file was collected from THIS build of the kernels (it records
     the hash of csrc/ + include/ it was measured on) and at this atom count; otherwise null."""
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json" if atoms == 50 else f"hbm_traffic_k{atoms}.json")
     try:
         from dl_attack_on_imagenet_amd.build import source_hash
         rec = json.load(open(tpath))

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(1024) void spd_inverse_kernel(const float* __restri
         const double piv = 1.0 / rowbuf[par][k];
         double rw[4], cl[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) rw[c] = rowbuf[par][4 * tj + c] * piv;         // scaled pivot row
+        for (int c = 0; c < 4; ++c) rw[c] = (4 * tj + c == k) ? piv : rowbuf[par][4 * tj + c] * piv;   // scaled pivot row; pivot -> 1/a_kk
 #pragma unroll
         for (int r = 0; r < 4; ++r) cl[r] = colbuf[par][4 * ti + r];
 #pragma unroll
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(1024) void spd_inverse_kernel(const float* __restri
             for (int c = 0; c < 4; ++c) {
                 const int j = 4 * tj + c;
                 double val;
-                if (i == k) val = (j == k) ? piv : rw[c];                          // pivot row: scaled; pivot: its reciprocal
+                if (i == k) val = rw[c];                                           // pivot row: scaled; pivot: its reciprocal
                 else val = ((j == k) ? 0.0 : t[r][c]) - cl[r] * rw[c];             // elimination (pivot column: -a_ik / a_kk)
                 t[r][c] = val;
             }
@@ -461,7 +461,8 @@ extern "C" int adil_pack_codes(const float* v, const int64_t* index, int B, int 
     if (nslabs < 0 || (vpt != nullptr && ((uintptr_t)vpt & 15))) return ADIL_EINVAL;
     const int Kp = round_up(K, 16), Bp = round_up(B, 32), A = adil_grad_code_rows(K);
     const int total = Bp * (vpt != nullptr ? A : Kp);
-    const dim3 grid((total + 255) / 256), block(256);
+    const int threads = nslabs > 0 ? 64 : 256;                   // slab sums: spread the latency-bound lanes over all CUs
+    const dim3 grid((total + threads - 1) / threads), block(threads);
     hipStream_t st = (hipStream_t)stream;
     if (vpt == nullptr || vpt_dtype == ADIL_F32)
         hipLaunchKernelGGL(pack_codes_kernel<float>, grid, block, 0, st, v, index, B, K, Kp, Bp, vp, pos, (float*)vpt, A, slabs,
@@ -532,7 +533,10 @@ static int launch_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, flo
                                hipStream_t st, const float* skip_if_below = nullptr, float skip_threshold = 0.0f,
                                float* clear = nullptr, const float* dyn = nullptr, const float* slabs = nullptr,
                                int nslabs = 0, int slab_rows = 0) {
-    const dim3 grid((N + 3) / 4), block(256);
+    // one wave per row; with the slab reduction inside, one wave per WORKGROUP: the batch rows each walk ~240 slabs in
+    // dependent rounds of 32 loads, and 512 single-wave workgroups spread over all CUs where 128 four-wave ones fill half
+    const int rows_per_block = nslabs > 0 ? 1 : 4;
+    const dim3 grid((N + rows_per_block - 1) / rows_per_block), block(64 * rows_per_block);
     if (K <= 64)
         hipLaunchKernelGGL(adamw_l1ball_kernel<1>, grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
                            max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear, dyn, slabs, nslabs, slab_rows);

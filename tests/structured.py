@@ -12,13 +12,16 @@ import torch
 import torch.nn.functional as F
 
 
-def structured_images(n, classes=10, seed=0, size=224, noise=0.10, cells=7):
-    """(images (n,3,size,size) in [0,1], labels (n,)): class c = a coarse cells x cells colour pattern, bilinearly
-    upsampled, plus per-pixel Gaussian noise."""
+def structured_images(n, classes=10, seed=0, size=224, noise=0.10, cells=7, draw=0):
+    """(images (n,3,size,size) in [0,1], labels (n,)): class c = a coarse cells x cells colour pattern (fixed by `seed`),
+    bilinearly upsampled, plus per-pixel Gaussian noise (`draw` selects an independent set of the same classes, e.g. a
+    held-out evaluation split)."""
     g = torch.Generator().manual_seed(seed)
     protos = torch.rand(classes, 3, cells, cells, generator=g)
     protos = F.interpolate(protos, size=(size, size), mode="bilinear", align_corners=False) * 0.6 + 0.2
     labels = torch.arange(n) % classes
+    if draw:
+        g = torch.Generator().manual_seed(seed * 7919 + 104729 * draw)
     images = (protos[labels] + noise * torch.randn(n, 3, size, size, generator=g)).clamp_(0.0, 1.0)
     return images, labels
 

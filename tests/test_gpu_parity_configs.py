@@ -200,7 +200,7 @@ def structured(tmp_path_factory):
 
 
 STRUCTURED_MARGIN = 10.0
-STRUCTURED_T = 100
+STRUCTURED_T = 300
 
 
 def test_config2_shared_gradient_steps_bf16_structured(structured):
@@ -223,34 +223,51 @@ def test_config2_shared_gradient_steps_bf16_structured(structured):
     assert fooled[-1][0] > 50                                             # images ARE being fooled along this trajectory
 
 
-def test_asr_parity_bf16_product_vs_fp32_reference_structured(structured):
-    """north_star's ASR criterion at the benchmarked dtype: the bf16 product (HIP kernels, bf16 streams, bf16 FusedResNet)
-    against the fp32 REFERENCE CONFIGURATION (fp32 oracle maths + plain fp32 ResNet-50, the same weights) on 512
-    structured images, 50 atoms, one batch, loss 'logits', eps 8/255, free-running for STRUCTURED_T iterations — until the
-    attack has saturated, because before saturation even two fp32 runs of the same maths sit a few pp apart (chaotic
-    trajectories; profiles/r03_parity_configs.md).  ASR as performance.py:238-246, each leg judged by the network it
-    attacked: within 1 pp (5 of 512 images).  The fooled-count lists of both legs are printed."""
-    from dl_attack_on_imagenet_amd import engine, ops
+def test_asr_parity_bf16_product_vs_fp32_reference_structured(structured, tmp_path):
+    """north_star's ASR criterion at the benchmarked dtype, as the reference measures it (demo_dL_attack.py:88-156): learn
+    the dictionary on a training split, then performance() = attack(x, y) — DDrague inference, 100 iterations — on a
+    held-out split, ASR = fooling rate over the correctly classified images (performance.py:154-177, :238-246).
+      A  the fp32 REFERENCE CONFIGURATION: fp32 oracle learner + oracle inference + plain fp32 ResNet-50
+      C  the PRODUCT: DictionaryLearner (HIP kernels, bf16 streams) + ADIL.forward through performance.performance over a
+         resident evaluation set + the bf16 FusedResNet (the same weights)
+    512 structured training and 512 held-out images, 50 atoms, one batch, loss 'logits', eps 8/255, STRUCTURED_T learning
+    iterations — run until the dictionary has saturated, because earlier even two fp32 runs of the same maths sit a few
+    pp apart (chaotic AdamW trajectories on a non-deterministic classifier backward; at 100 iterations: A 96.5 %, C 99.4 %,
+    and the ORACLE's inference with C's dictionary on the fp32 network 99.8 % — the gap is which dictionary was reached,
+    not precision; profiles/r03_parity_configs.md).  Asserted: |ASR_A - ASR_C| <= 1 pp, and the two inference paths on
+    the SAME dictionary (C's) within 1 pp as well.  The fooled-count lists of both learners are printed."""
+    import performance as perf
+    from attacks import ADIL
+    from dl_attack_on_imagenet_amd import engine, loader
     from oracle import adil_oracle as O
-    n, k, T = 512, 50, STRUCTURED_T
+    from structured import structured_images
+    n, k, T, S = 512, 50, STRUCTURED_T, 100
     images, ref, fast = structured["images"], structured["ref"], structured["fast"]
+    held, held_labels = structured_images(n, classes=10, seed=3, draw=1)
     g = torch.Generator().manual_seed(33)
     d0 = -1 + 2 * torch.rand(3, 224, 224, k, generator=g)
     v0 = O.project_onto_l1_ball(torch.rand(n, k, generator=g), EPS)
     batches = [list(range(n))]
     da, va, fa, _ = _oracle_run(O, ref, images, d0, v0, T, EPS, batches, dev=DEV)
     dc, vc, fc, _ = _hip_run(engine, fast, images, d0, v0, T, EPS, batches, dtype=torch.bfloat16)
-    x32 = images.to(DEV)
-    x16 = x32.to(torch.bfloat16)
-    asr_a = _asr(ref, O.synth(x32, da, va), x32)
-    adv_c = ops.synth(x16, dc, ops.pack_codes(vc, None, n), n)
-    asr_c = _asr(fast, adv_c, x16)
-    asr_c_fp32_judge = _asr(ref, adv_c.float(), x32)
-    _note("asr_parity_structured", dict(T=T, margin_min=structured["margin_min"], fooled_A_fp32_reference=fa, fooled_C_bf16_product=fc,
-                                        asr_A=asr_a, asr_C=asr_c, asr_C_judged_by_the_fp32_network=asr_c_fp32_judge))
-    assert asr_a >= 0.5                                                    # a working attack, not 0 == 0
-    assert abs(asr_a - asr_c) <= 0.01, (asr_a, asr_c)
-    assert abs(asr_a - asr_c_fp32_judge) <= 0.01, (asr_a, asr_c_fp32_judge)
+    held_batches = [(held[lo:lo + 128].to(DEV), held_labels[lo:lo + 128].to(DEV)) for lo in range(0, n, 128)]
+    perf_a = O.performance(lambda xx, yy: O.forward_supervised_ddrague(ref, xx, da, EPS, S, "logits"), ref, held_batches)
+    perf_a_with_dc = O.performance(lambda xx, yy: O.forward_supervised_ddrague(ref, xx, dc, EPS, S, "logits"), ref, held_batches)
+    torch.save([dc.cpu(), vc.cpu(), [], [], torch.tensor(0.)], os.path.join(tmp_path, "ImageNet_structured.bin"))
+    atk = ADIL(fast, eps=EPS, n_atoms=k, attack="supervised", model_name="structured", loss="logits", steps_inference=S,
+               dict_dir=str(tmp_path), stream_dtype=torch.bfloat16)
+    resident = loader.ResidentBatches(torch.utils.data.TensorDataset(held, held_labels), held_labels, 128, DEV, torch.bfloat16)
+    perf_c = perf.performance(atk, fast, resident)
+    _note("asr_parity_structured", dict(T=T, steps_inference=S, margin_min=structured["margin_min"],
+                                        fooled_while_learning_A_fp32_reference=fa, fooled_while_learning_C_bf16_product=fc,
+                                        asr_A=perf_a["fooling_rate"], asr_C=perf_c["fooling_rate"],
+                                        asr_oracle_inference_fp32_net_with_the_products_dictionary=perf_a_with_dc["fooling_rate"],
+                                        rmse_A=perf_a["rmse"], rmse_C=perf_c["rmse"], samples=perf_a["num_samples"]))
+    assert perf_a["num_samples"] == n                                      # every held-out image is correctly classified
+    assert perf_a["fooling_rate"] >= 0.9                                   # a working attack, not 0 == 0
+    assert abs(perf_a["fooling_rate"] - perf_c["fooling_rate"]) <= 0.01, (perf_a, perf_c)
+    assert abs(perf_a_with_dc["fooling_rate"] - perf_c["fooling_rate"]) <= 0.01, (perf_a_with_dc, perf_c)
+    assert abs(perf_a["rmse"] - perf_c["rmse"]) <= 0.05 * perf_a["rmse"]
 
 
 class _AsFp32(torch.nn.Module):
@@ -328,3 +345,23 @@ def test_other_classifiers_through_the_learner(name, k, b, tmp_path):
 
 
 OTHER_MARGIN = 2.0
+
+
+def test_vit_b16_learner_step_at_bench_size():
+    """Regression guard of the round-1 GPU fault: ViT-B/16 through the learner at the bench's 512 images per
+    GPU, 100 atoms, bf16 — the shape at which this PyTorch-ROCm build's nn.MultiheadAttention call (its fused fast path /
+    SDPA) faulted; the zoo computes the same attention with plain matmuls (zoo._EncoderBlock._attention).  Two steps,
+    finite results, the invariants of the update."""
+    from dl_attack_on_imagenet_amd import engine, ops, zoo
+    n, k = 512, 100
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(n, 3, 224, 224, generator=g).to(DEV).to(torch.bfloat16)
+    d0 = (-1 + 2 * torch.rand(3, 224, 224, k, generator=g)).to(DEV)
+    v0 = ops.l1ball_project_(torch.rand(n, k, generator=g).to(DEV), EPS)
+    model = zoo.build_classifier("vit_b_16", seed=1, device=DEV, dtype=torch.bfloat16)
+    learner = engine.DictionaryLearner(d0, v0, EPS, 0.01, "logits", False, 50.0)
+    index = torch.arange(n, device=DEV)
+    fooled = [int(learner.step(model, x, index)[1]) for _ in range(2)]
+    assert torch.isfinite(learner.d).all() and torch.isfinite(learner.v).all()
+    assert float(learner.d.abs().max()) <= 1.0 and float(learner.v.abs().sum(1).max()) <= EPS * (1 + 1e-5)
+    assert all(0 <= f <= n for f in fooled)

@@ -59,11 +59,11 @@ def main():
     # reduction in adamw_l1ball; stand-alone ops.grad calls of the micro-benchmark still launch both helpers, and the
     # reduce launches that follow the fused kernel there are attributed to it)
     groups = {"synth": [k for k in rows if k.startswith("synth_mfma")],
-              "grad": [k for k in rows if k.startswith(("grad_fused_mfma", "grad_v_reduce after grad_fused_mfma", "transpose_codes"))],
+              "grad": [k for k in rows if k.startswith("grad_fused_mfma")],
               "adamw_clamp_": [k for k in rows if k.startswith("adamw_clamp")],
               "adamw_l1ball_": [k for k in rows if k.startswith("adamw_l1ball")],
               "zstep_": [k for k in rows if k.startswith("zstep_mfma")],
-              "grad[z D_dagger^T]": [k for k in rows if k.startswith(("grad_v_mfma_kernel<float", "grad_v_f32_kernel", "grad_v_reduce after grad_v_f32"))],
+              "grad[z D_dagger^T]": [k for k in rows if k.startswith(("grad_v_mfma_kernel<float", "grad_v_f32_kernel"))],
               "pack_codes": [k for k in rows if k.startswith("pack_codes")]}
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from dl_attack_on_imagenet_amd.build import source_hash

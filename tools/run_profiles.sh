@@ -1,22 +1,34 @@
 #!/bin/bash
-# rocprofv3 evidence of one round, run on the GPU box from the repo root:  bash tools/run_profiles.sh r02
-# kernel-trace/stats runs and the two PMC passes are separate invocations (counters are never combined with traces
-# beyond --kernel-trace); the program itself follows `--` (no env/bash hop).
+# rocprofv3 evidence of one round, run on the GPU box from the repo root:  bash tools/run_profiles.sh r03
+# kernel-trace/stats runs and the PMC passes are separate invocations (counters are never combined with traces beyond
+# --kernel-trace); the program itself follows `--` (no env/bash hop).  Every table comes from the SAME tree: the hash of
+# the kernel sources is written next to them and into hbm_traffic*.json (bench.py reports roofline.traffic only for it).
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 root=$(pwd)
 export TMPDIR=/tmp
 out=$root/gpurun_out
 mkdir -p $out
+python3 -c "import sys; sys.path.insert(0, '$root'); from dl_attack_on_imagenet_amd.build import source_hash; print(source_hash())" > $out/${tag}_kernel_source_hash.txt || exit 1
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag}_learn -- python3 $root/bench.py --steps 20 --warmup 5 --cpu-baseline 0 > $out/prof_${tag}_learn.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag}_inference -- python3 $root/bench.py --mode inference --steps 20 --warmup 3 --cpu-baseline 0 > $out/prof_${tag}_inference.log 2>&1 || exit 1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_${tag}_FETCH_SIZE -- python3 $root/tools/bench_kernels.py > $out/pmc_${tag}_fetch.log 2>&1 || exit 1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_${tag}_WRITE_SIZE -- python3 $root/tools/bench_kernels.py > $out/pmc_${tag}_write.log 2>&1 || exit 1
+stats() {   # name, description, bench arguments...
+    name=$1; desc=$2; shift 2
+    rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag}_$name -- python3 $root/bench.py "$@" --cpu-baseline 0 > $out/prof_${tag}_$name.log 2>&1 || return 1
+    python3 $root/tools/prof_summary.py $out/prof_${tag}_$name $out/${tag}_${name}_bench_stats.md "$desc, rocprofv3 --kernel-trace --stats" > /dev/null
+}
+stats learn "bench.py (learn, ResNet-50, 512 images, 50 atoms, bf16 streams)" --steps 20 --warmup 5 || exit 1
+stats inference "bench.py --mode inference (DDrague iteration, ResNet-50, 512 images, 50 atoms, bf16 streams, fp32 z)" --mode inference --steps 20 --warmup 3 || exit 1
+stats learn_k100 "bench.py --atoms 100 (learn, ResNet-50, 512 images, 100 atoms = the reference's n_atoms, bf16 streams)" --atoms 100 --steps 20 --warmup 5 || exit 1
+stats inference_k100 "bench.py --mode inference --atoms 100 (DDrague iteration, 100 atoms)" --mode inference --atoms 100 --steps 20 --warmup 3 || exit 1
+stats transfer "bench.py --mode transfer (configs[3]: full attack(x, y) of 100 DDrague iterations, 100 atoms, against ResNet-50 + six targets scored, 512 images per batch)" --mode transfer --steps 2 --warmup 1 || exit 1
+for K in 50 100; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    K=$K rocprofv3 --pmc $C --kernel-trace --output-format csv -d $out/pmc_${tag}_k${K}_$C -- python3 $root/tools/bench_kernels.py > $out/pmc_${tag}_k${K}_$C.log 2>&1 || exit 1
+  done
+done
 cd $root
-python3 tools/prof_summary.py $out/prof_${tag}_learn $out/${tag}_learn_stats.md "bench.py (learn, ResNet-50, 512 images, 50 atoms, bf16 streams), rocprofv3 --kernel-trace --stats" > /dev/null
-python3 tools/prof_summary.py $out/prof_${tag}_inference $out/${tag}_inference_stats.md "bench.py --mode inference (DDrague iteration, ResNet-50, 512 images, 50 atoms, bf16 streams, fp32 z), rocprofv3 --kernel-trace --stats" > /dev/null
 python3 tools/step_breakdown.py $out/prof_${tag}_learn 23 > $out/${tag}_learn_step_breakdown.txt
 python3 tools/step_breakdown.py $out/prof_${tag}_learn 3 > $out/${tag}_learn_step_breakdown_cached_labels.txt
-python3 tools/pmc_traffic.py $out/pmc_${tag}_FETCH_SIZE $out/pmc_${tag}_WRITE_SIZE $out/${tag}_hbm_traffic.json > $out/${tag}_hbm_traffic.txt
+K=50 python3 tools/pmc_traffic.py $out/pmc_${tag}_k50_FETCH_SIZE $out/pmc_${tag}_k50_WRITE_SIZE $out/${tag}_hbm_traffic.json > $out/${tag}_hbm_traffic.txt
+K=100 python3 tools/pmc_traffic.py $out/pmc_${tag}_k100_FETCH_SIZE $out/pmc_${tag}_k100_WRITE_SIZE $out/${tag}_hbm_traffic_k100.json > $out/${tag}_hbm_traffic_k100.txt
 echo profiles done
