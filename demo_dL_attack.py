@@ -40,9 +40,9 @@ def build_parser():
     p.add_argument('--loss', default='logits', choices=['logits', 'ce'])
     p.add_argument('--method', default='gd', choices=['gd', 'alter'])
     p.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'])
-    p.add_argument('--cache-labels', type=int, default=0,
-                   help='1: compute the clean pseudo-label of a training image once instead of in every epoch '
-                        '(one classifier forward less per learning step; 0 = the reference op sequence)')
+    p.add_argument('--cache-labels', type=int, default=1,
+                   help='1 (default): compute the clean pseudo-label of a training image once instead of in every epoch '
+                        '(one classifier forward less per learning step; measured result-neutral); 0 = the reference op sequence')
     p.add_argument('--val-every', type=int, default=1,
                    help='validate every this many epochs (0 = after the last epoch only); the dictionary file is the same')
     p.add_argument('--fast-classifier', type=int, default=1,

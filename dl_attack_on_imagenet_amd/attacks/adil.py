@@ -63,8 +63,10 @@ class ADIL(Attack):
       dict_dir       folder of the dictionary file (default 'trained_dicts')
       shuffle_seed   seed of the per-epoch global batches of the data-parallel learner (identical on every rank)
       cache_labels   learners: compute the clean pseudo-label of an image once (first epoch) instead of in every epoch
-                     (engine.LabelCache; saves one of the two classifier forwards per step; default False = the
-                     reference's op sequence)
+                     (engine.LabelCache; saves one of the two classifier forwards per step).  Default True since round 3:
+                     the label of a frozen eval-mode classifier is a constant of the image, and 30 000 re-labellings in
+                     shuffled / ragged batches changed none (profiles/r03_label_stability.md); False = the reference's op
+                     sequence, which recomputes it every epoch (adil.py:172)
       val_every      validate (100 AdamW iterations per validation batch, adil.py:199-205) every this many epochs; the
                      reference does it after EVERY epoch but only prints the value and stores the last one, so any
                      setting writes the same dictionary file; 0 = after the last epoch only.  Default 1 (as upstream)
@@ -79,7 +81,7 @@ class ADIL(Attack):
                  data_train=None, data_val=None, trials=10, attack='supervised', model_name=None, step_size=0.01,
                  is_distributed=False, steps_in=None, loss='ce', method='gd', warm_start=False, kappa=50,
                  steps_inference=30, alpha=None, init_d=None, init_v=None, epoch_batches=None, val_batches=None,
-                 stream_dtype=None, dict_dir='trained_dicts', shuffle_seed=0, use_graph=None, cache_labels=False, val_every=1):
+                 stream_dtype=None, dict_dir='trained_dicts', shuffle_seed=0, use_graph=None, cache_labels=True, val_every=1):
         super().__init__("ADIL", model.eval())
         self.norm = norm.lower()
         self.eps = eps
@@ -230,8 +232,8 @@ class ADIL(Attack):
             loss_full = torch.zeros((), dtype=torch.float32, device=self.device)
             fooled = torch.zeros((), dtype=torch.int64, device=self.device)
             for index, x, lab in self._labelled_batches(train, self._epoch_order(n_img, batch_size, self._epoch_batches, iteration)):
-                if self._use_graph and lab is None:
-                    ls, fl = learner.step_graphed(self.model, x, index)
+                if self._use_graph:
+                    ls, fl = learner.step_graphed(self.model, x, index, lab)
                 else:
                     ls, fl = learner.step(self.model, x, index, lab)                       # adil.py:168-191
                 loss_full += ls

@@ -123,11 +123,13 @@ class LabelCache:
 
     The learners of the reference recompute `model(x).argmax` for the same clean images in every epoch (adil.py:172,
     268, 295).  The classifier is frozen and in eval mode, so the label is a constant of the image: after the first
-    epoch the second forward of every step is pure recomputation (a third of the step's classifier time).  Opt-in
-    (`ADIL(cache_labels=True)`), because the reference's value comes from whatever batch the image is in that epoch and a
-    library may round the logits of an image differently in a different batch — a near-tie could flip; the default keeps
-    the reference's op sequence.  Which rows are known is tracked on the host (the batch order is host data), so a lookup
-    costs no synchronisation."""
+    epoch the second forward of every step is pure recomputation (a third of the step's classifier time).  The one way the
+    cached value could differ from the reference's — a library rounding an image's logits differently in a different
+    batch and flipping a near-tie — was measured (round 3, tools/exp_label_stability.py, profiles/r03_label_stability.md):
+    10 000 images re-labelled in 3 shuffled batch orders incl. a ragged last batch, bf16 FusedResNet-50 and plain fp32
+    ResNet-50: 0 labels changed.  So it is the DEFAULT of the learners (`ADIL(cache_labels=True)`); cache_labels=False
+    is the reference's op sequence.  Which rows are known is tracked on the host (the batch order is
+    host data), so a lookup costs no synchronisation."""
 
     def __init__(self, n: int, device):
         self.labels = torch.full((n,), -1, dtype=torch.int64, device=device)
@@ -171,7 +173,7 @@ class DictionaryLearner:
         # configs[4]: the D.V contraction of the synthesis on fp8 MFMAs.  Legal here because every row of v lives in
         # the l1 ball of radius eps after update_v (so |v| <= eps bounds the code scale) and |d| <= 1 after update_d.
         self.fp8_absmax = float(eps) if fp8_synth else None
-        self._graph = None                       # (graph, x, index, loss, fooled, batch size) once `use_graph` captured a step
+        self._graph = None                       # (graph, x, index, loss, fooled, batch size, labels) once `use_graph` captured a step
         self._graph_warm = 0
         self._dyn_d = self._dyn_v = None
         self._pending = None                     # handle of the step's all-reduce between forward_backward and update_d
@@ -247,34 +249,40 @@ class DictionaryLearner:
                           dyn=self._dyn_v)
 
     # -- the whole step as ONE hipGraph launch (launch-bound configurations) ------------------------------------ #
-    def step_graphed(self, model, x: Tensor, index: Tensor):
+    def step_graphed(self, model, x: Tensor, index: Tensor, labels: Optional[Tensor] = None):
         """`step()` replayed from a hipGraph: the ~200 launches of a step (classifier forward twice, backward, the five
         ADiL kernels) become one graph launch — for launch-bound uses (small crops, tiny classifiers; configs[0] itself,
         resnet18 on 32 images of 224x224, turned out GPU-bound: 7.2 ms either way).  The first two calls run eagerly (library autotuning must not
         happen under capture), the third captures the step for this batch size and replays it; later calls copy x / index
         into the graph's static inputs and replay.  AdamW's step-dependent scalars reach the recorded launches through
-        device memory (`dyn_scalars`).  A different batch size, a reducer (the collective is not captured) or an empty
-        batch falls back to the eager step.  Results are bit-identical to `step()` (tests/test_gpu_adil.py)."""
+        device memory (`dyn_scalars`).  `labels`: the cached clean pseudo-labels of the batch (engine.LabelCache); the
+        recording then holds one classifier forward less.  A different batch size, a change between given and recomputed
+        labels, a reducer (the collective is not captured) or an empty batch falls back to the eager step.  Results are
+        bit-identical to `step()` (tests/test_gpu_adil.py)."""
         index = index.to(device=self.v.device, dtype=torch.int64)
         b = x.shape[0]
-        if self.reducer is not None or b == 0 or (self._graph is not None and self._graph[5] != b):
-            return self.step(model, x, index)
+        if self.reducer is not None or b == 0 or (self._graph is not None and
+                                                  (self._graph[5] != b or (self._graph[6] is None) != (labels is None))):
+            return self.step(model, x, index, labels)
         if self._graph is None:
             if self._graph_warm < 2:
                 self._graph_warm += 1
-                return self.step(model, x, index)
+                return self.step(model, x, index, labels)
             self._dyn_d = self.sched_d.enable_device_scalars(self.d.device)
             self._dyn_v = self.sched_v.enable_device_scalars(self.v.device)
             gx, gi = x.clone(), index.clone()
+            gl = labels.clone() if labels is not None else None
             t_d, t_v = self.sched_d.t, self.sched_v.t
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                ls, fooled = self.step(model, gx, gi)
+                ls, fooled = self.step(model, gx, gi, gl)
             self.sched_d.t, self.sched_v.t = t_d, t_v            # capture records, it does not execute: no step was taken
-            self._graph = (graph, gx, gi, ls, fooled, b)
-        graph, gx, gi, ls, fooled, _ = self._graph
+            self._graph = (graph, gx, gi, ls, fooled, b, gl)
+        graph, gx, gi, ls, fooled, _, gl = self._graph
         gx.copy_(x)
         gi.copy_(index)
+        if gl is not None:
+            gl.copy_(labels)
         self.sched_d.next_to_device()                            # this step's scalars, ordered before the replay
         self.sched_v.next_to_device()
         graph.replay()

@@ -496,7 +496,7 @@ def test_bench_starts_its_own_ranks(launcher, tmp_path):
     assert out["config"]["global_batch"] == 64 and out["value"] > 0
     assert abs(out["value"] - 2 * 32 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     assert "cpu_baseline" not in out and out["roofline"]["bound"] == "hbm"
-    assert out["config"]["cached_labels_variant"]["images_per_sec"] > 0
+    assert out["config"]["recomputed_labels_variant"]["images_per_sec"] > 0      # the reference's op sequence, timed beside the headline
 
 
 def test_transfer_evaluation_data_parallel(tmp_path):
@@ -566,14 +566,17 @@ def test_graphed_learner_step_is_bit_identical():
     images = torch.rand(20, 3, 32, 32, generator=g).to(DEV)
     d0 = (-1 + 2 * torch.rand(3, 32, 32, 6, generator=g)).to(DEV)
     v0 = ops.l1ball_project_(torch.rand(20, 6, generator=g).to(DEV), 0.3)
-    for schedule in ([list(range(20))] * 8,
-                     [[3, 1, 4, 15, 9, 2, 6, 5], [8, 7, 0, 19, 18, 17, 16, 14], [13, 12, 11, 10]] * 3):
+    full = engine.predict(net, images)
+    for schedule, cached in (([list(range(20))] * 8, False),
+                             ([[3, 1, 4, 15, 9, 2, 6, 5], [8, 7, 0, 19, 18, 17, 16, 14], [13, 12, 11, 10]] * 3, False),
+                             ([[3, 1, 4, 15, 9, 2, 6, 5], [8, 7, 0, 19, 18, 17, 16, 14], [13, 12, 11, 10]] * 3, True)):
         a = engine.DictionaryLearner(d0.clone(), v0.clone(), 0.3, 0.01, "logits")
         b = engine.DictionaryLearner(d0.clone(), v0.clone(), 0.3, 0.01, "logits")
         for idx in schedule:
             index = torch.tensor(idx, device=DEV)
-            la, fa = a.step(net, images[index].contiguous(), index)
-            lb, fb = b.step_graphed(net, images[index].contiguous(), index)
+            lab = full[index] if cached else None                  # cached pseudo-labels (the learners' default): one forward less in the recording
+            la, fa = a.step(net, images[index].contiguous(), index, lab)
+            lb, fb = b.step_graphed(net, images[index].contiguous(), index, lab)
             assert float(la) == float(lb) and int(fa) == int(fb)
         assert b._graph is not None                                # a graph was captured and replayed
         for x, y in ((a.d, b.d), (a.v, b.v), (a.m_d, b.m_d), (a.s_d, b.s_d), (a.m_v, b.m_v), (a.s_v, b.s_v)):
