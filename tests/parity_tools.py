@@ -19,15 +19,22 @@ first-order amplification bound computed from the measured gradient difference â
 import torch
 
 
-def bf16_scale_ulps(a: torch.Tensor, b: torch.Tensor, *operands: torch.Tensor) -> float:
+def bf16_scale_ulps(a: torch.Tensor, b: torch.Tensor, *operands: torch.Tensor):
     """max |a - b| in units of one bf16 ulp at the scale of the LARGEST of |a|, |b| and the operands that formed them
-    (x + delta can cancel to ~0, where an ulp of the result itself says nothing about the arithmetic)."""
+    (x + delta can cancel to ~0, where an ulp of the result itself says nothing about the arithmetic).  The binade comes
+    from frexp (exact; a device log2 is not correctly rounded at powers of two).  Returns (ratio, description of the
+    worst element)."""
     a32, b32 = a.float(), b.float()
     scale = torch.maximum(a32.abs(), b32.abs())
     for o in operands:
         scale = torch.maximum(scale, o.float().abs())
-    ulp = torch.exp2(torch.floor(torch.log2(scale.clamp_min(2.0 ** -126))) - 7)       # bf16: 8 significant bits
-    return float(((a32 - b32).abs() / ulp).max())
+    _, e = torch.frexp(scale.clamp_min(2.0 ** -120))              # scale = m * 2^e, m in [0.5, 1)
+    ulp = torch.ldexp(torch.ones_like(scale), e - 8)              # bf16: 8 significant bits -> spacing 2^(e-1-7)
+    ratio = (a32 - b32).abs() / ulp
+    i = int(ratio.flatten().argmax())
+    worst = dict(index=i, ulps=float(ratio.flatten()[i]), a=float(a32.flatten()[i]), b=float(b32.flatten()[i]),
+                 operands=[float(o.float().flatten()[i]) for o in operands])
+    return worst["ulps"], worst
 
 
 def force_state(learner, d, v, sd, sv):
@@ -54,8 +61,10 @@ def shared_gradient_step(O, engine, model, learner, twin, x_stream, index, label
     # (1) synthesis
     xt_o = O.synth(x_stream.float(), dop, vop)
     xt_h, codes = learner.synthesize(x_stream, index)
+    synth_worst = None
     if bf16:
-        synth_err = bf16_scale_ulps(xt_h, xt_o.to(torch.bfloat16), x_stream)
+        synth_err, synth_worst = bf16_scale_ulps(xt_h, xt_o.to(torch.bfloat16), x_stream)
+        synth_worst["oracle_before_rounding"] = float(xt_o.flatten()[synth_worst["index"]])
     else:
         synth_err = float((xt_h - xt_o).abs().max())
     # (2) the classifier, ONCE (on the product's batch); the label decisions on the oracle's own batch, forward only
@@ -82,7 +91,7 @@ def shared_gradient_step(O, engine, model, learner, twin, x_stream, index, label
     well = vhat >= 1e-6
     dd = (learner.d - d).abs()
     amplification = sd.lr / sd.eps          # |d(step)/d(grad)| at its largest: step = lr g / (|g| + eps) at t = 1, |g| << eps
-    return dict(synth=synth_err, fooled=fooled, fooled_on_oracle_synth=fooled_o, loss=float(ls),
+    return dict(synth=synth_err, synth_worst=synth_worst, fooled=fooled, fooled_on_oracle_synth=fooled_o, loss=float(ls),
                 grad_d_rel=e_gd, grad_v_rel=e_gv,
                 update_dD=float((twin.d - d).abs().max()), update_dV=float((twin.v - v).abs().max()),
                 dV=float((learner.v - v).abs().max()), dD=float(dd.max()),
@@ -90,11 +99,13 @@ def shared_gradient_step(O, engine, model, learner, twin, x_stream, index, label
                 dD_bound=4.0 * amplification * abs_gd + 1e-7, frac_well_conditioned=float(well.float().mean()))
 
 
-def worst_of(records, skip=("fooled", "fooled_on_oracle_synth", "loss", "frac_well_conditioned")):
+def worst_of(records, skip=("fooled", "fooled_on_oracle_synth", "loss", "frac_well_conditioned", "synth_worst")):
     out = {}
     for r in records:
         for key, val in r.items():
             if key not in skip:
                 out[key] = max(out.get(key, 0.0), val)
+    if records and records[0].get("synth_worst") is not None:
+        out["synth_worst_element"] = max((r["synth_worst"] for r in records), key=lambda w: w["ulps"])
     out["frac_well_conditioned_min"] = min(r["frac_well_conditioned"] for r in records)
     return out

@@ -36,10 +36,10 @@ def _note(name, payload):
     try:
         os.makedirs(OUT, exist_ok=True)
         with open(os.path.join(OUT, f"parity_configs_{STAMP}.jsonl"), "a") as f:
-            f.write(json.dumps({"test": name, **payload}) + "\n")
+            f.write(json.dumps({"test": name, **payload}, default=float) + "\n")
     except OSError:
         pass
-    print(name, json.dumps(payload))
+    print(name, json.dumps(payload, default=float))
 
 
 def _oracle_run(O, model, images, d0, v0, T, eps, batches, loss="logits", dev="cpu"):
@@ -257,7 +257,7 @@ def test_asr_parity_bf16_product_vs_fp32_reference_structured(structured, tmp_pa
     atk = ADIL(fast, eps=EPS, n_atoms=k, attack="supervised", model_name="structured", loss="logits", steps_inference=S,
                dict_dir=str(tmp_path), stream_dtype=torch.bfloat16)
     resident = loader.ResidentBatches(torch.utils.data.TensorDataset(held, held_labels), held_labels, 128, DEV, torch.bfloat16)
-    perf_c = perf.performance(atk, fast, resident)
+    perf_c = {key: float(val) for key, val in perf.performance(atk, fast, resident).items()}
     _note("asr_parity_structured", dict(T=T, steps_inference=S, margin_min=structured["margin_min"],
                                         fooled_while_learning_A_fp32_reference=fa, fooled_while_learning_C_bf16_product=fc,
                                         asr_A=perf_a["fooling_rate"], asr_C=perf_c["fooling_rate"],
