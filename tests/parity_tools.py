@@ -7,7 +7,7 @@ same logits / input gradient g go to the oracle's update (oracle.apply_gradient_
 run-to-run backward noise â€” which used to sit inside the comparison because each side called the classifier itself â€”
 is gone.  Three checks per step, each isolating one kernel group:
 
-  synth     x + D v                          HIP vs oracle (fp32: absolute; bf16 streams: in bf16 ulps at the operands' scale)
+  synth     x + D v                          HIP vs oracle (fp32: absolute; bf16 streams: one bf16 ulp of the result + fp32 accumulation noise)
   gradient  grad_d = g^T V, grad_v = g D     HIP vs oracle on the identical g, relative to the largest entry
   update    AdamW + clamp / + l1 projection  HIP kernels fed the ORACLE's gradient vs the oracle's update: identical inputs,
                                              so any difference is the update kernels' own arithmetic
@@ -19,22 +19,22 @@ first-order amplification bound computed from the measured gradient difference â
 import torch
 
 
-def bf16_scale_ulps(a: torch.Tensor, b: torch.Tensor, *operands: torch.Tensor):
-    """max |a - b| in units of one bf16 ulp at the scale of the LARGEST of |a|, |b| and the operands that formed them
-    (x + delta can cancel to ~0, where an ulp of the result itself says nothing about the arithmetic).  The binade comes
-    from frexp (exact; a device log2 is not correctly rounded at powers of two).  Returns (ratio, description of the
-    worst element)."""
+def bf16_result_error(a: torch.Tensor, b: torch.Tensor, x: torch.Tensor, abs_terms: torch.Tensor):
+    """How far two bf16 results a, b of x + sum_k v_k D_k are apart, in units of what two CORRECT evaluations may differ by:
+    one bf16 ulp of the result (an fp32 sum that lands on the other side of a rounding boundary) plus the fp32
+    accumulation noise 2^-20 * (|x| + sum_k |v_k D_k|) (the order of the K + 1 additions; it dominates where the sum
+    cancels to ~0, e.g. a clamped pixel x = 0 with a perturbation of 3e-8 formed from terms of 1e-4).  The binade comes
+    from frexp (exact; a device log2 is not correctly rounded at powers of two).  Returns (max ratio, worst element)."""
     a32, b32 = a.float(), b.float()
-    scale = torch.maximum(a32.abs(), b32.abs())
-    for o in operands:
-        scale = torch.maximum(scale, o.float().abs())
-    _, e = torch.frexp(scale.clamp_min(2.0 ** -120))              # scale = m * 2^e, m in [0.5, 1)
-    ulp = torch.ldexp(torch.ones_like(scale), e - 8)              # bf16: 8 significant bits -> spacing 2^(e-1-7)
-    ratio = (a32 - b32).abs() / ulp
+    mag = torch.maximum(a32.abs(), b32.abs()).clamp_min(2.0 ** -120)
+    _, e = torch.frexp(mag)                                         # mag = m * 2^e, m in [0.5, 1)
+    ulp = torch.ldexp(torch.ones_like(mag), e - 8)                  # bf16: 8 significant bits -> spacing 2^(e-1-7)
+    allowed = ulp + 2.0 ** -20 * (x.float().abs() + abs_terms)
+    ratio = (a32 - b32).abs() / allowed
     i = int(ratio.flatten().argmax())
-    worst = dict(index=i, ulps=float(ratio.flatten()[i]), a=float(a32.flatten()[i]), b=float(b32.flatten()[i]),
-                 operands=[float(o.float().flatten()[i]) for o in operands])
-    return worst["ulps"], worst
+    worst = dict(index=i, ratio=float(ratio.flatten()[i]), a=float(a32.flatten()[i]), b=float(b32.flatten()[i]),
+                 x=float(x.float().flatten()[i]), sum_abs_terms=float(abs_terms.flatten()[i]))
+    return worst["ratio"], worst
 
 
 def force_state(learner, d, v, sd, sv):
@@ -63,14 +63,24 @@ def shared_gradient_step(O, engine, model, learner, twin, x_stream, index, label
     xt_h, codes = learner.synthesize(x_stream, index)
     synth_worst = None
     if bf16:
-        synth_err, synth_worst = bf16_scale_ulps(xt_h, xt_o.to(torch.bfloat16), x_stream)
-        synth_worst["oracle_before_rounding"] = float(xt_o.flatten()[synth_worst["index"]])
+        abs_terms = O.synth(torch.zeros_like(xt_o), dop.abs(), vop.abs())      # sum_k |v_k D_k| per pixel
+        synth_err, synth_worst = bf16_result_error(xt_h, xt_o.to(torch.bfloat16), x_stream, abs_terms)
+        del abs_terms
     else:
         synth_err = float((xt_h - xt_o).abs().max())
     # (2) the classifier, ONCE (on the product's batch); the label decisions on the oracle's own batch, forward only
     out, ls, g = engine.input_gradient(model, xt_h, labels, loss, -1.0, kappa, "sum")
     fooled = int((out.argmax(-1) != labels).sum())
-    fooled_o = int((engine.predict(model, xt_o.to(x_stream.dtype)) != labels).sum())
+    with torch.no_grad():
+        out_o = engine._classify(model, xt_o.to(x_stream.dtype)).float()
+    fooled_o = int((out_o.argmax(-1) != labels).sum())
+    # images on which the two synthesised batches (equal up to the bound above) are classified differently, and how close
+    # to the decision boundary they sit: top-2 margin, the smaller of the two batches' values
+    differ = out.float().argmax(-1) != out_o.argmax(-1)
+    n_differ, differ_margin = int(differ.sum()), 0.0
+    if n_differ:
+        t_h, t_o = out.float().topk(2, dim=1).values, out_o.topk(2, dim=1).values
+        differ_margin = float(torch.minimum(t_h[:, 0] - t_h[:, 1], t_o[:, 0] - t_o[:, 1])[differ].max())
     # (3) the gradient contractions on the SAME g
     gd_o, gv_o = O.grad_dv(g.float(), dop, vop)
     gd_h, gvb = learner.backward(g, codes)
@@ -92,6 +102,7 @@ def shared_gradient_step(O, engine, model, learner, twin, x_stream, index, label
     dd = (learner.d - d).abs()
     amplification = sd.lr / sd.eps          # |d(step)/d(grad)| at its largest: step = lr g / (|g| + eps) at t = 1, |g| << eps
     return dict(synth=synth_err, synth_worst=synth_worst, fooled=fooled, fooled_on_oracle_synth=fooled_o, loss=float(ls),
+                label_decisions_differ=n_differ, differing_margin=differ_margin,
                 grad_d_rel=e_gd, grad_v_rel=e_gv,
                 update_dD=float((twin.d - d).abs().max()), update_dV=float((twin.v - v).abs().max()),
                 dV=float((learner.v - v).abs().max()), dD=float(dd.max()),
@@ -106,6 +117,6 @@ def worst_of(records, skip=("fooled", "fooled_on_oracle_synth", "loss", "frac_we
             if key not in skip:
                 out[key] = max(out.get(key, 0.0), val)
     if records and records[0].get("synth_worst") is not None:
-        out["synth_worst_element"] = max((r["synth_worst"] for r in records), key=lambda w: w["ulps"])
+        out["synth_worst_element"] = max((r["synth_worst"] for r in records), key=lambda w: w["ratio"])
     out["frac_well_conditioned_min"] = min(r["frac_well_conditioned"] for r in records)
     return out

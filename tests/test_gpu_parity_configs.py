@@ -80,7 +80,7 @@ def _asr(model, adv, clean, chunk=64):
     return float(torch.cat(flips).mean())
 
 
-def _teacher_forced(O, engine, model, images, d0, v0, T, dtype, loss="logits"):
+def _teacher_forced(O, engine, model, images, d0, v0, T, dtype, loss="logits", eps=EPS):
     """T shared-gradient steps along the oracle's trajectory from (d0, v0) on one full batch. Returns the per-step records."""
     n = images.shape[0]
     x = images.to(DEV).to(dtype).contiguous()
@@ -88,15 +88,15 @@ def _teacher_forced(O, engine, model, images, d0, v0, T, dtype, loss="logits"):
     labels = engine.predict(model, x)
     d, v = d0.clone().to(DEV), v0.clone().to(DEV)
     sd, sv = O.AdamWState(d, 0.01), O.AdamWState(v, 0.01)
-    learner = engine.DictionaryLearner(d.clone(), v.clone(), EPS, 0.01, loss, False, 50.0)
-    twin = engine.DictionaryLearner(d.clone(), v.clone(), EPS, 0.01, loss, False, 50.0)
-    return [shared_gradient_step(O, engine, model, learner, twin, x, index, labels, d, v, sd, sv, EPS, loss) for _ in range(T)]
+    learner = engine.DictionaryLearner(d.clone(), v.clone(), eps, 0.01, loss, False, 50.0)
+    twin = engine.DictionaryLearner(d.clone(), v.clone(), eps, 0.01, loss, False, 50.0)
+    return [shared_gradient_step(O, engine, model, learner, twin, x, index, labels, d, v, sd, sv, eps, loss) for _ in range(T)]
 
 
 def _assert_kernel_bounds(w, bf16):
     """The stated tolerances of the kernel-isolating legs (maxima over all steps of a trajectory)."""
     if bf16:
-        assert w["synth"] <= 1.0, w                       # one bf16 ulp at the operands' scale
+        assert w["synth"] <= 1.0, w                       # one bf16 ulp of the result + fp32 accumulation noise (parity_tools)
     else:
         assert w["synth"] <= 1e-5, w                      # fp32: absolute on O(1) pixels (measured 3e-7 ... 6e-7)
     assert w["grad_d_rel"] <= 1e-5 and w["grad_v_rel"] <= 1e-5, w          # contractions on the identical g
@@ -126,7 +126,7 @@ def test_config1_shared_gradient_steps_fp32():
     fooled = [(r["fooled"], r["fooled_on_oracle_synth"]) for r in rec]
     _note("config1_shared_gradient", dict(worst=w, fooled_product_vs_oracle_synth=fooled))
     _assert_kernel_bounds(w, bf16=False)
-    assert all(a == b for a, b in fooled), fooled                          # bit-exact label decisions
+    assert all(a == b for a, b in fooled) and w["label_decisions_differ"] == 0, fooled   # bit-exact label decisions
     assert fooled[0][0] <= 4 and fooled[-1][0] >= 28                       # the attack works on this workload (2 -> 31 of 32)
 
 
@@ -219,7 +219,13 @@ def test_config2_shared_gradient_steps_bf16_structured(structured):
     _note("config2_shared_gradient_bf16_structured", dict(worst=w, fooled_product_vs_oracle_synth=fooled,
                                                            margin_min=structured["margin_min"]))
     _assert_kernel_bounds(w, bf16=True)
-    assert all(a == b for a, b in fooled), fooled
+    # label decisions on the product's vs the oracle's synthesised batch: the two batches differ by at most one bf16 ulp in
+    # single pixels, and the attack parks images ON the decision boundary, so late in the run an image or two can fall on
+    # either side.  Stated: at most 2 of 512 images per step, each within 2 % of the median clean margin of the boundary,
+    # and none at all while fewer than half of the images are fooled
+    clean_margin = structured["margin_median"]
+    assert w["label_decisions_differ"] <= 2 and w["differing_margin"] <= 0.02 * clean_margin, w
+    assert all(r["label_decisions_differ"] == 0 for r in rec if r["fooled"] < 256), fooled
     assert fooled[-1][0] > 50                                             # images ARE being fooled along this trajectory
 
 
@@ -310,41 +316,40 @@ def test_config2_free_running_reported():
     assert max(abs(c - b_) for c, b_ in zip(fc, fb)) <= 0.08 * n
 
 
-@pytest.mark.parametrize("name,k,b", [("densenet121", 50, 16), ("vit_b_16", 100, 16)])
-def test_other_classifiers_through_the_learner(name, k, b, tmp_path):
+@pytest.mark.parametrize("name,k,b,eps,T", [("densenet121", 50, 16, 32 / 255, 16), ("vit_b_16", 100, 16, 8 / 255, 30)])
+def test_other_classifiers_through_the_learner(name, k, b, eps, T, tmp_path):
     """configs[2] / configs[4] classifiers (DenseNet-121; ViT-B/16 = 197 tokens) through the learner, on 16 STRUCTURED images
-    with a fitted head and a small clean margin (so that images are actually fooled within a dozen iterations — the
-    round-2 DenseNet leg compared 0 == 0): 12 teacher-forced shared-gradient steps fp32 (kernel bounds, label decisions
-    equal at every step, > 0 fooled at the end), then the free-running bf16 product: invariants of the update and a
+    (4 classes) with a fitted head, at an eps / iteration count at which images ARE fooled (the round-2 DenseNet leg compared
+    0 == 0; `tests/experiments/exp_other_classifiers.py`: DenseNet-121 needs eps 32/255 — at 8/255 it fools 3 of 16 in 60
+    iterations — ViT-B/16 fools 10 of 16 by iteration 15 at 8/255).  T teacher-forced shared-gradient steps in fp32: the
+    kernel bounds, label decisions equal at every step; then the free-running bf16 product: invariants of the update and a
     non-trivial fooled count."""
     from dl_attack_on_imagenet_amd import engine, zoo
     from oracle import adil_oracle as O
     from structured import fit_centroid_head, structured_images
-    T = 12
     images, labels = structured_images(b, classes=4, seed=7, noise=0.15)
     model = zoo.build_classifier(name, seed=1, device=DEV)
-    margins, pred = fit_centroid_head(model, images, labels, 4, DEV, target_margin=OTHER_MARGIN)
+    margins, pred = fit_centroid_head(model, images, labels, 4, DEV, target_margin=2.0)
     assert bool((pred == labels).all())
     path = os.path.join(str(tmp_path), "fitted.pt")
     torch.save(model[-1].state_dict(), path)
     g = torch.Generator().manual_seed(5)
     d0 = -1 + 2 * torch.rand(3, 224, 224, k, generator=g)
-    v0 = O.project_onto_l1_ball(torch.rand(b, k, generator=g), EPS)
-    rec = _teacher_forced(O, engine, model, images, d0, v0, T, torch.float32)
+    v0 = O.project_onto_l1_ball(torch.rand(b, k, generator=g), eps)
+    rec = _teacher_forced(O, engine, model, images, d0, v0, T, torch.float32, eps=eps)
     w = worst_of(rec)
     fooled = [(r["fooled"], r["fooled_on_oracle_synth"]) for r in rec]
-    _assert_kernel_bounds(w, bf16=False)
-    assert all(a == c for a, c in fooled), fooled
     model16 = zoo.build_classifier(name, seed=1, weights=path, device=DEV, dtype=torch.bfloat16)
-    d16, v16, f16, _ = _hip_run(engine, model16, images, d0, v0, T, EPS, [list(range(b))], dtype=torch.bfloat16)
-    _note(f"learner_{name}", dict(worst=w, fooled_fp32_product_vs_oracle_synth=fooled, fooled_bf16_free_running=f16,
+    d16, v16, f16, _ = _hip_run(engine, model16, images, d0, v0, T, eps, [list(range(b))], dtype=torch.bfloat16)
+    _note(f"learner_{name}", dict(eps=eps, T=T, worst=w, fooled_fp32_product_vs_oracle_synth=fooled, fooled_bf16_free_running=f16,
                                   margin_min=float(margins.min())))
-    assert fooled[-1][0] > 0 and f16[-1] > 0                               # images ARE fooled: the equality above is not 0 == 0
+    _assert_kernel_bounds(w, bf16=False)
+    assert all(a == c for a, c in fooled) and w["label_decisions_differ"] == 0, fooled
+    assert fooled[-1][0] >= 4 and f16[-1] >= 4                             # images ARE fooled: the equality above is not 0 == 0
     assert torch.isfinite(d16).all() and torch.isfinite(v16).all()
-    assert float(d16.abs().max()) <= 1.0 and float(v16.abs().sum(1).max()) <= EPS * (1 + 1e-5)
+    assert float(d16.abs().max()) <= 1.0 and float(v16.abs().sum(1).max()) <= eps * (1 + 1e-5)
 
 
-OTHER_MARGIN = 2.0
 
 
 def test_vit_b16_learner_step_at_bench_size():
