@@ -5,6 +5,7 @@
 # the kernel sources is written next to them and into hbm_traffic*.json (bench.py reports roofline.traffic only for it).
 set -o pipefail
 tag=${1:-r03}
+phase=${2:-all}          # stats | pmc | lines | all   (one gpurun call holds 20 minutes: stats and pmc+lines fit one each)
 root=$(pwd)
 export TMPDIR=/tmp
 out=$root/gpurun_out
@@ -16,19 +17,33 @@ stats() {   # name, description, bench arguments...
     rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag}_$name -- python3 $root/bench.py "$@" --cpu-baseline 0 > $out/prof_${tag}_$name.log 2>&1 || return 1
     python3 $root/tools/prof_summary.py $out/prof_${tag}_$name $out/${tag}_${name}_bench_stats.md "$desc, rocprofv3 --kernel-trace --stats" > /dev/null
 }
+if [ "$phase" = "stats" ] || [ "$phase" = "all" ]; then
 stats learn "bench.py (learn, ResNet-50, 512 images, 50 atoms, bf16 streams)" --steps 20 --warmup 5 || exit 1
 stats inference "bench.py --mode inference (DDrague iteration, ResNet-50, 512 images, 50 atoms, bf16 streams, fp32 z)" --mode inference --steps 20 --warmup 3 || exit 1
 stats learn_k100 "bench.py --atoms 100 (learn, ResNet-50, 512 images, 100 atoms = the reference's n_atoms, bf16 streams)" --atoms 100 --steps 20 --warmup 5 || exit 1
 stats inference_k100 "bench.py --mode inference --atoms 100 (DDrague iteration, 100 atoms)" --mode inference --atoms 100 --steps 20 --warmup 3 || exit 1
 stats transfer "bench.py --mode transfer (configs[3]: full attack(x, y) of 100 DDrague iterations, 100 atoms, against ResNet-50 + six targets scored, 512 images per batch)" --mode transfer --steps 2 --warmup 1 || exit 1
+cd $root
+python3 tools/step_breakdown.py $out/prof_${tag}_learn 23 > $out/${tag}_learn_step_breakdown.txt
+python3 tools/step_breakdown.py $out/prof_${tag}_learn 3 > $out/${tag}_learn_step_breakdown_recomputed_labels.txt
+fi
+if [ "$phase" = "pmc" ] || [ "$phase" = "all" ]; then
+cd /tmp
 for K in 50 100; do
   for C in FETCH_SIZE WRITE_SIZE; do
     K=$K rocprofv3 --pmc $C --kernel-trace --output-format csv -d $out/pmc_${tag}_k${K}_$C -- python3 $root/tools/bench_kernels.py > $out/pmc_${tag}_k${K}_$C.log 2>&1 || exit 1
   done
 done
 cd $root
-python3 tools/step_breakdown.py $out/prof_${tag}_learn 23 > $out/${tag}_learn_step_breakdown.txt
-python3 tools/step_breakdown.py $out/prof_${tag}_learn 3 > $out/${tag}_learn_step_breakdown_cached_labels.txt
 K=50 python3 tools/pmc_traffic.py $out/pmc_${tag}_k50_FETCH_SIZE $out/pmc_${tag}_k50_WRITE_SIZE $out/${tag}_hbm_traffic.json > $out/${tag}_hbm_traffic.txt
 K=100 python3 tools/pmc_traffic.py $out/pmc_${tag}_k100_FETCH_SIZE $out/pmc_${tag}_k100_WRITE_SIZE $out/${tag}_hbm_traffic_k100.json > $out/${tag}_hbm_traffic_k100.txt
-echo profiles done
+cp $out/${tag}_hbm_traffic.json profiles/hbm_traffic.json        # on the GPU box: the bench lines below then carry roofline.traffic
+cp $out/${tag}_hbm_traffic_k100.json profiles/hbm_traffic_k100.json
+fi
+if [ "$phase" = "lines" ] || [ "$phase" = "all" ]; then
+cd $root
+python3 bench.py > $out/${tag}_bench_line.json 2> $out/${tag}_bench_line.err || exit 1
+python3 bench.py --mode inference > $out/${tag}_bench_line_inference.json 2> $out/${tag}_bench_line_inference.err || exit 1
+python3 bench.py --mode transfer > $out/${tag}_bench_line_transfer.json 2> $out/${tag}_bench_line_transfer.err || exit 1
+fi
+echo profiles $phase done
