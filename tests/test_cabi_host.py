@@ -337,3 +337,35 @@ def test_demo_cast_loader_keeps_the_loader_interface():
         got = list(cast)
         assert [x.shape[0] for x, _ in got] == [3, 3, 1] and all(x.dtype == torch.bfloat16 for x, _ in got)
         assert torch.equal(torch.cat([y for _, y in got]), torch.arange(7))
+
+
+def test_bench_defaults_by_mode_and_traffic_is_tied_to_the_build(tmp_path, monkeypatch):
+    """bench.py: (i) the per-mode defaults (learn / inference: configs[1]'s 50 atoms, 100 steps; transfer: the reference's
+    100 atoms, 4 batches, 100 DDrague iterations; cached pseudo-labels by default); (ii) `roofline.traffic` is reported only
+    when profiles/hbm_traffic*.json was measured on THIS build of the kernels: a file recorded for another
+    source hash, or for another atom count, gives None."""
+    import json
+    import bench
+    from dl_attack_on_imagenet_amd.build import source_hash
+    monkeypatch.setattr("sys.argv", ["bench.py"])
+    a = bench.parse_args()
+    assert (a.mode, a.steps, a.warmup, a.atoms, a.cache_labels, a.gpus) == ("learn", 100, 5, 50, 1, 1)
+    monkeypatch.setattr("sys.argv", ["bench.py", "--mode", "transfer"])
+    a = bench.parse_args()
+    assert (a.steps, a.warmup, a.atoms, a.steps_inference) == (4, 1, 100, 100)
+    monkeypatch.setattr("sys.argv", ["bench.py", "--mode", "transfer", "--steps", "2", "--atoms", "10"])
+    a = bench.parse_args()
+    assert (a.steps, a.atoms) == (2, 10)
+    os.makedirs(tmp_path / "profiles")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.measured_traffic("synth", 50) is None                                   # no file
+    rec = {"_source": {"kernel_source_hash": source_hash(), "atoms": 50}, "synth": 341.0e6}
+    json.dump(rec, open(tmp_path / "profiles" / "hbm_traffic.json", "w"))
+    assert bench.measured_traffic("synth", 50) == 341.0e6
+    assert bench.measured_traffic("zstep_", 50) is None                                  # group not measured
+    assert bench.measured_traffic("synth", 100) is None                                  # other atom count: its own file
+    rec["_source"]["kernel_source_hash"] = "0" * 16                                      # measured on another build
+    json.dump(rec, open(tmp_path / "profiles" / "hbm_traffic.json", "w"))
+    assert bench.measured_traffic("synth", 50) is None
+    a50 = bench.algorithmic_bytes(512, 150528, 50, 512, 2, "learn")
+    assert a50["synth"] == 2 * 512 * 150528 * 2 + 150528 * 50 * 4 + 512 * 50 * 4          # DESIGN §4: 338.5 MB

@@ -354,18 +354,19 @@ def test_other_classifiers_through_the_learner(name, k, b, eps, T, tmp_path):
 
 
 
-def test_vit_b16_learner_step_at_bench_size():
-    """Regression guard of the round-1 GPU fault: ViT-B/16 through the learner at the bench's 512 images per
-    GPU, 100 atoms, bf16 — the shape at which this PyTorch-ROCm build's nn.MultiheadAttention call (its fused fast path /
-    SDPA) faulted; the zoo computes the same attention with plain matmuls (zoo._EncoderBlock._attention).  Two steps,
-    finite results, the invariants of the update."""
+@pytest.mark.parametrize("name,k", [("vit_b_16", 100), ("densenet121", 50)])
+def test_other_classifiers_learner_step_at_bench_size(name, k):
+    """configs[2] / configs[4] classifiers at the bench's 512 images per GPU, bf16 streams (they were only
+    exercised at 16 images).  For ViT-B/16 this is also the regression guard of the round-1 GPU fault: the shape
+    at which this PyTorch-ROCm build's nn.MultiheadAttention call (its fused fast path / SDPA) faulted; the zoo computes the
+    same attention with plain matmuls (zoo._EncoderBlock._attention).  Two steps, finite results, the invariants of the update."""
     from dl_attack_on_imagenet_amd import engine, ops, zoo
-    n, k = 512, 100
+    n = 512
     g = torch.Generator().manual_seed(9)
     x = torch.rand(n, 3, 224, 224, generator=g).to(DEV).to(torch.bfloat16)
     d0 = (-1 + 2 * torch.rand(3, 224, 224, k, generator=g)).to(DEV)
     v0 = ops.l1ball_project_(torch.rand(n, k, generator=g).to(DEV), EPS)
-    model = zoo.build_classifier("vit_b_16", seed=1, device=DEV, dtype=torch.bfloat16)
+    model = zoo.build_classifier(name, seed=1, device=DEV, dtype=torch.bfloat16)
     learner = engine.DictionaryLearner(d0, v0, EPS, 0.01, "logits", False, 50.0)
     index = torch.arange(n, device=DEV)
     fooled = [int(learner.step(model, x, index)[1]) for _ in range(2)]
