@@ -26,6 +26,9 @@ stats transfer "bench.py --mode transfer (configs[3]: full attack(x, y) of 100 D
 cd $root
 python3 tools/step_breakdown.py $out/prof_${tag}_learn 23 > $out/${tag}_learn_step_breakdown.txt
 python3 tools/step_breakdown.py $out/prof_${tag}_learn 3 > $out/${tag}_learn_step_breakdown_recomputed_labels.txt
+# gpurun merges at most 64 MiB back: the per-launch traces (tens of MB each) are condensed above; the per-kernel stats
+# CSVs of rocprofv3 itself stay next to the tables
+find $out -path "*prof_${tag}_*" -name "*kernel_trace.csv" -delete
 fi
 if [ "$phase" = "pmc" ] || [ "$phase" = "all" ]; then
 cd /tmp
