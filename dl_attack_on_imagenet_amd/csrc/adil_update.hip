@@ -267,16 +267,20 @@ __global__ __launch_bounds__(256) void gather_images_kernel(const S* __restrict_
 }
 
 // ---- K7: inverse of the K x K Gram matrix (symmetric positive definite) ------ //
-// One workgroup of 32 x 32 threads, in-place Gauss-Jordan without pivoting (stable for SPD matrices) in fp64: the
-// result is the correctly rounded fp32 inverse for any conditioning an fp32 LAPACK inverse can handle at all.
-// Round 3: the matrix lives in REGISTERS — thread (ti, tj) owns the 4 x 4 tile of rows 4ti.., columns 4tj.. (K <= 128),
-// padded with the identity — and a step only moves the pivot row and the pivot column through LDS (2 x 128 doubles,
-// double-buffered: ONE barrier per step).  The round-2 kernel kept the whole matrix in LDS and pushed all K^2 entries
-// through it in every step (240 KB of LDS traffic and four barriers per step: 46 us at K = 50, ~250 us at K = 100).
-__global__ __launch_bounds__(1024) void spd_inverse_kernel(const float* __restrict__ a, int K, float* __restrict__ out) {
+// One workgroup, in-place Gauss-Jordan without pivoting (stable for SPD matrices) in fp64: the result is the correctly
+// rounded fp32 inverse for any conditioning an fp32 LAPACK inverse can handle at all.
+// Round 3: the matrix lives in REGISTERS — thread (ti, tj) of a Kt x Kt grid, Kt = ceil(K / 4), owns the 4 x 4 tile of
+// rows 4ti.., columns 4tj.. (identity beyond K) — and a step only moves the pivot row and the pivot column through LDS
+// (2 x 128 doubles, double-buffered: ONE barrier per step).  Only the Kt^2 threads that own a tile are launched (K = 50:
+// 169 threads = 3 waves; K = 100: 625 = 10 waves): a step is ~100 fp64 instructions per wave, and fp64 issues at a
+// quarter of the fp32 rate, so idle tiles are not free.  The round-2 kernel kept the whole matrix in LDS and pushed all
+// K^2 entries through it in every step (240 KB of LDS traffic and four barriers per step: 46 us at K = 50, ~250 us at
+// K = 100).
+__global__ __launch_bounds__(1024) void spd_inverse_kernel(const float* __restrict__ a, int K, int Kt, float* __restrict__ out) {
     __shared__ double rowbuf[2][128];
     __shared__ double colbuf[2][128];
-    const int tj = threadIdx.x & 31, ti = threadIdx.x >> 5;
+    const bool active = (int)threadIdx.x < Kt * Kt;              // the tail of the last wave only keeps the barriers company
+    const int ti = active ? threadIdx.x / Kt : 0, tj = active ? threadIdx.x - ti * Kt : 0;
     double t[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(1024) void spd_inverse_kernel(const float* __restri
     }
     for (int k = 0; k < K; ++k) {
         const int par = k & 1, kt = k >> 2, kr = k & 3;
-        if (ti == kt) {                                    // owners of pivot row k publish their four entries of it
+        if (active && ti == kt) {                          // owners of pivot row k publish their four entries of it
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 double val = t[0][c];
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(1024) void spd_inverse_kernel(const float* __restri
                 rowbuf[par][4 * tj + c] = val;
             }
         }
-        if (tj == kt) {                                    // owners of pivot column k
+        if (active && tj == kt) {                          // owners of pivot column k
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 double val = t[r][0];
@@ -307,6 +311,7 @@ __global__ __launch_bounds__(1024) void spd_inverse_kernel(const float* __restri
             }
         }
         __syncthreads();                                   // the only barrier of the step (buffers alternate)
+        if (!active) continue;
         const double piv = 1.0 / rowbuf[par][k];
         double rw[4], cl[4];
 #pragma unroll
@@ -326,6 +331,7 @@ __global__ __launch_bounds__(1024) void spd_inverse_kernel(const float* __restri
             }
         }
     }
+    if (!active) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -503,7 +509,8 @@ extern "C" int adil_gather_images(const void* src, int src_dtype, const int64_t*
 extern "C" int adil_spd_inverse(const float* a, int K, float* out, void* stream) {
     ADIL_ENTER();
     if (!a || !out || K <= 0 || K > ADIL_MAX_ATOMS) return ADIL_EINVAL;
-    hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, K, out);
+    const int Kt = (K + 3) / 4;
+    hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(round_up(Kt * Kt, 64)), 0, (hipStream_t)stream, a, K, Kt, out);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
