@@ -904,3 +904,17 @@ def test_bench_transfer_mode_line(tmp_path):
     assert set(line["config"]["transfer_fooling_rates"]) == {"resnet18", "densenet121", "googlenet", "inception_v3", "mobilenet_v2", "vgg11"}
     assert line["roofline"]["kernel"] == "zstep_" and line["roofline"]["launches_timed"] == 2 * 5
     assert line["config"]["ddrague_iterations_run_per_batch"] == 5
+    # two ranks (one-GPU rehearsal: gloo, shared card): performance.py deals batch i to rank i % 2, each rank keeps only its
+    # own batches resident, the final sums are all-reduced; the line says which backend it ran on
+    env = dict(os.environ, ADIL_DIST_BACKEND="gloo", ADIL_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "transfer", "--model", "resnet18",
+                        "--batch", "4", "--atoms", "10", "--steps", "1", "--warmup", "0", "--steps-inference", "3", "--cpu-baseline", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["config"]["collective"]["backend"] == "gloo"
+    assert abs(line["value"] - 2 * 4 * 1 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
