@@ -243,10 +243,28 @@ def cpu_baseline(args, P_shape, dev):
         dt = time.perf_counter() - t0
         what = f"{args.cpu_steps} learning step(s) of the CPU oracle (oracle/adil_oracle.py learn_step_a)"
         value = b * args.cpu_steps / dt
+        # "separately, seconds per step of the dictionary ops alone" — the reference's op sequence without
+        # the classifier (synthesis, backward through the tensordot for a given dLoss/dx, AdamW on D and all code rows,
+        # l1 projection, clamp) at the FULL batch of the workload; compare with `dictionary_path_ms_per_step` of the GPU
+        bf = args.batch
+        gen = torch.Generator().manual_seed(1)
+        xf, gf = torch.rand(bf, *P_shape, generator=gen), torch.randn(bf, *P_shape, generator=gen) * 1e-3
+        vf = O.project_onto_l1_ball(torch.rand(bf, k, generator=gen), 8 / 255)
+        df = d.clone()
+        sdf, svf, idx = O.AdamWState(df, 0.01), O.AdamWState(vf, 0.01), torch.arange(bf)
+        t1 = time.perf_counter()
+        O.synth(xf, df, vf[idx])
+        O.apply_gradient_a(gf, idx, df, vf, sdf, svf, 8 / 255)
+        dict_only_ms = (time.perf_counter() - t1) * 1e3
+        del xf, gf
     out = {"value": value, "unit": "adversarial images/sec", "cores": threads, "kind": "port",
            "sample": f"{what}, fp32, torch {torch.__version__} CPU, {threads} threads of {os.cpu_count()} logical "
                      f"cores; configs[1] shape ({args.model}, {k} atoms, {P_shape[1]}x{P_shape[2]}) on {b} of its "
                      f"{args.batch} images per step; {dt:.1f} s"}
+    if args.mode == "learn":
+        out["dictionary_ops_alone_ms_per_step"] = dict_only_ms
+        out["dictionary_ops_alone_note"] = (f"synthesis + backward through the tensordot + AdamW(D, all rows of V) + l1 projection + clamp "
+                                            f"on the host cores at the full batch of {args.batch} images, no classifier (one step)")
     if args.cpu_config1 and args.mode == "learn":
         out["config1"] = cpu_config1(dev)
     return out
