@@ -24,12 +24,13 @@ for name, n, k, T, dt, seed in (("resnet18", 32, 10, 20, torch.float32, 21), ("r
     d, v = d0.clone().to(dev), v0.clone().to(dev)
     sd, sv = O.AdamWState(d, 0.01), O.AdamWState(v, 0.01)
     learner = engine.DictionaryLearner(d.clone(), v.clone(), eps, 0.01, "logits", False, 50.0)
+    twin = engine.DictionaryLearner(d.clone(), v.clone(), eps, 0.01, "logits", False, 50.0)
     worst = {}
     fooled = []
     for it in range(T):
-        r = shared_gradient_step(O, engine, model, learner, x, index, labels, d, v, sd, sv, eps, "logits")
+        r = shared_gradient_step(O, engine, model, learner, twin, x, index, labels, d, v, sd, sv, eps, "logits")
         fooled.append((r["fooled"], r["fooled_on_oracle_synth"]))
         for key, val in r.items():
-            if key not in ("fooled", "fooled_on_oracle_synth", "loss"):
+            if key not in ("fooled", "fooled_on_oracle_synth", "loss", "synth_worst"):
                 worst[key] = max(worst.get(key, 0), val)
     print(json.dumps(dict(model=name, n=n, k=k, T=T, dtype=str(dt), worst=worst, fooled=fooled)), flush=True)
