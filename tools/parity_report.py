@@ -29,11 +29,11 @@ if len(runs) > 1:
             print("| " + " | ".join(keys) + " |\n|" + "---|" * len(keys))
             print("| " + " | ".join(f"{fmt(float(min(r['worst'][k] for r in recs)))} … {fmt(float(max(r['worst'][k] for r in recs)))}" for k in keys) + " |\n")
         elif name == "asr_parity_structured":
-            print("**asr_parity_structured** (ASR through the reference's pipeline, 512 held-out structured images)\n")
-            print("| run | ASR A (fp32 reference configuration) | ASR C (bf16 product) | oracle inference with C's dictionary | \\|A − C\\| |\n|---|---|---|---|---|")
+            print("**asr_parity_structured** (ASR through the reference's pipeline on held-out structured images)\n")
+            print("| run | held-out images | ASR A (fp32 reference configuration) | ASR C (bf16 product) | fp32 inference of the other side with C's dictionary | \\|A − C\\| |\n|---|---|---|---|---|---|")
             for i, r in enumerate(recs):
                 a, c = r["asr_A"], r["asr_C"]
-                print(f"| {i + 1} | {100 * a:.2f} % | {100 * c:.2f} % | {100 * r['asr_oracle_inference_fp32_net_with_the_products_dictionary']:.2f} % | {100 * abs(a - c):.2f} pp |")
+                print(f"| {i + 1} | {r.get('samples', 512)} | {100 * a:.2f} % | {100 * c:.2f} % | {100 * r['asr_oracle_inference_fp32_net_with_the_products_dictionary']:.2f} % | {100 * abs(a - c):.2f} pp |")
             print()
 for path in sys.argv[1:]:
     print(f"## run `{path.split('/')[-1]}`\n")
