@@ -247,10 +247,13 @@ def test_asr_parity_bf16_product_vs_fp32_reference_structured(structured, tmp_pa
     C 98.8-100 %, |A - C| 0.2-0.8 pp; 200 inference iterations instead of 100 change nothing) — hence 1024 held-out
     images.  Measured over nine runs: |ASR_A - ASR_C| = 0.2 ... 0.8 pp, i.e. within the 1 pp asked for (VERDICT r2 #1c) every
     time; the assertion guards at 1.5 pp so that the run-to-run noise of two chaotic trajectories cannot turn the suite red.
-    The same-dictionary cross-check (the ORACLE's fp32 inference with C's dictionary vs the product's bf16 inference) is
-    where the dtype itself shows: 0.0 ... 1.3 pp lower in bf16, because x + delta and dLoss/dx are stored at 8 significant
-    bits (a perturbation component of 0.002 on a pixel of 0.8 rounds away) — reported, guarded at 2.5 pp.  The fooled-count
-    lists of both learners are printed."""
+    Same-dictionary cross-checks (C's dictionary through every inference path, tests/experiments/exp_inference_dtype.py):
+      * the ORACLE's inference (fp32, fp32 network) vs the PRODUCT's inference in fp32 (HIP kernels, fp32 streams, the same
+        fp32 network): 99.80 % = 99.80 % — asserted within north_star's 0.5 pp;
+      * the product's bf16 configuration: 0.0 ... 1.3 pp lower, and it is the bf16 CLASSIFIER, not the streams or the kernels
+        (fp32 streams + the bf16 network behind an fp32 interface: 98.73 %; bf16 streams + bf16 network: 98.93 %) — reported,
+        guarded at 2.5 pp.
+    The fooled-count lists of both learners are printed."""
     import performance as perf
     from attacks import ADIL
     from dl_attack_on_imagenet_amd import engine, loader
@@ -274,14 +277,20 @@ def test_asr_parity_bf16_product_vs_fp32_reference_structured(structured, tmp_pa
                dict_dir=str(tmp_path), stream_dtype=torch.bfloat16)
     resident = loader.ResidentBatches(torch.utils.data.TensorDataset(held, held_labels), held_labels, 128, DEV, torch.bfloat16)
     perf_c = {key: float(val) for key, val in perf.performance(atk, fast, resident).items()}
+    atk32 = ADIL(ref, eps=EPS, n_atoms=k, attack="supervised", model_name="structured", loss="logits", steps_inference=S,
+                 dict_dir=str(tmp_path))
+    resident32 = loader.ResidentBatches(torch.utils.data.TensorDataset(held, held_labels), held_labels, 128, DEV)
+    perf_p32 = {key: float(val) for key, val in perf.performance(atk32, ref, resident32).items()}
     _note("asr_parity_structured", dict(T=T, steps_inference=S, margin_min=structured["margin_min"],
                                         fooled_while_learning_A_fp32_reference=fa, fooled_while_learning_C_bf16_product=fc,
                                         asr_A=perf_a["fooling_rate"], asr_C=perf_c["fooling_rate"],
                                         asr_oracle_inference_fp32_net_with_the_products_dictionary=perf_a_with_dc["fooling_rate"],
+                                        asr_product_inference_fp32_streams_fp32_net_with_the_products_dictionary=perf_p32["fooling_rate"],
                                         rmse_A=perf_a["rmse"], rmse_C=perf_c["rmse"], samples=perf_a["num_samples"]))
     assert perf_a["num_samples"] >= 0.99 * n_eval                          # (nearly) every held-out image is correctly classified
     assert perf_a["fooling_rate"] >= 0.9                                   # a working attack, not 0 == 0
     assert abs(perf_a["fooling_rate"] - perf_c["fooling_rate"]) <= 0.015, (perf_a, perf_c)           # measured 0.2-0.8 pp
+    assert abs(perf_a_with_dc["fooling_rate"] - perf_p32["fooling_rate"]) <= 0.005, (perf_a_with_dc, perf_p32)   # measured 0.0 pp
     assert abs(perf_a_with_dc["fooling_rate"] - perf_c["fooling_rate"]) <= 0.025, (perf_a_with_dc, perf_c)   # measured 0.0-1.3 pp
     assert abs(perf_a["rmse"] - perf_c["rmse"]) <= 0.05 * perf_a["rmse"]
 
