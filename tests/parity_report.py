@@ -1,5 +1,5 @@
 """profiles/rNN_parity_configs.md from the jsonl the config-level parity tests write (gpurun_out/parity_configs_*.jsonl).
-usage: python tools/parity_report.py gpurun_out/parity_configs_<stamp>.jsonl [more.jsonl ...] > profiles/r03_parity_configs.md"""
+usage: python tests/parity_report.py gpurun_out/parity_configs_<stamp>.jsonl [more.jsonl ...] > profiles/r03_parity_configs.md"""
 import json
 import sys
 
