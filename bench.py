@@ -597,6 +597,11 @@ def main():
     }
     if other_variant is not None:
         out["config"]["recomputed_labels_variant" if args.cache_labels else "cached_labels_variant"] = other_variant
+        # both pseudo-label policies at the top level as well, so that neither number has to be dug out of `config`:
+        # `value` follows --cache-labels (default 1); the reference's 2 fwd + 1 bwd sequence is always here
+        out["value_reference_op_sequence_recomputed_labels"] = (other_variant if args.cache_labels else
+                                                                {"images_per_sec": out["value"], "ms_per_step": out["ms_per_step"]})["images_per_sec"]
+        out["value_cached_labels"] = out["value"] if args.cache_labels else other_variant["images_per_sec"]
     if rank == 0 and world == 1 and args.cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, shape, dev)
     if rank == 0:
