@@ -33,7 +33,9 @@ if len(runs) > 1:
             print("| run | held-out images | ASR A (fp32 reference configuration) | ASR C (bf16 product) | fp32 inference of the other side with C's dictionary | \\|A − C\\| |\n|---|---|---|---|---|---|")
             for i, r in enumerate(recs):
                 a, c = r["asr_A"], r["asr_C"]
-                print(f"| {i + 1} | {r.get('samples', 512)} | {100 * a:.2f} % | {100 * c:.2f} % | {100 * r['asr_oracle_inference_fp32_net_with_the_products_dictionary']:.2f} % | {100 * abs(a - c):.2f} pp |")
+                x = r["asr_oracle_inference_fp32_net_with_the_products_dictionary"]
+                nx = r.get("cross_check_images", r.get("samples", 512))
+                print(f"| {i + 1} | {r.get('samples', 512)} | {100 * a:.2f} % | {100 * c:.2f} % | {100 * x:.2f} % (of {nx}) | {100 * abs(a - c):.2f} pp |")
             print()
 for path in sys.argv[1:]:
     print(f"## run `{path.split('/')[-1]}`\n")
