@@ -429,24 +429,52 @@ __global__ __launch_bounds__(1024) void atom_l1ball_kernel(float* __restrict__ d
 // ---- K7: the Gram matrix and D * M^T are MFMA kernels in adil_contract.hip (adil_gram, adil_dict_rightmul) ---- //
 
 // ---- K12: per-image evaluation sums ----------------------------------------- //
-template <typename T>
-__global__ __launch_bounds__(256) void image_metrics_kernel(const T* __restrict__ adv, const T* __restrict__ x, int P,
-                                                            float* __restrict__ sq_err, float* __restrict__ sq_norm) {
-    __shared__ float red[2][4];
+// One workgroup of 1024 threads per image; 16-byte loads (8 bf16 / 4 fp32 elements) when the image size and both base
+// pointers allow (VEC), element-wise otherwise; per-thread sums -> wave sums -> the 16 wave partials added in a fixed order
+// (bitwise reproducible).  Round 3: the round-1 kernel (256 threads per image, 2-byte loads) read its 2 x 154 MB at
+// 1.1 TB/s (272 us per 512-image batch in profiles/r03_transfer_bench_stats.md).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(1024) void image_metrics_kernel(const T* __restrict__ adv, const T* __restrict__ x, int P,
+                                                             float* __restrict__ sq_err, float* __restrict__ sq_norm) {
+    __shared__ float red[2][16];
     const size_t base = (size_t)blockIdx.x * P;
     float e = 0.0f, q = 0.0f;
-    for (int p = threadIdx.x; p < P; p += 256) {
-        const float xv = Elem<T>::load(x, base + p);
-        const float dv = Elem<T>::load(adv, base + p) - xv;
-        e += dv * dv;
-        q += xv * xv;
+    if constexpr (VEC) {
+        constexpr int N = 16 / sizeof(T);
+        const uint4* av = reinterpret_cast<const uint4*>(adv + base);
+        const uint4* xv = reinterpret_cast<const uint4*>(x + base);
+        for (int i = threadIdx.x; i < P / N; i += 1024) {
+            const uint4 a4 = av[i], x4 = xv[i];
+            const unsigned aw[4] = {a4.x, a4.y, a4.z, a4.w}, xw[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (sizeof(T) == 4) {
+                    const float xf = __uint_as_float(xw[j]), dv = __uint_as_float(aw[j]) - xf;
+                    e += dv * dv; q += xf * xf;
+                } else {
+                    const float x0 = __uint_as_float(xw[j] << 16), x1 = __uint_as_float(xw[j] & 0xffff0000u);
+                    const float d0 = __uint_as_float(aw[j] << 16) - x0, d1 = __uint_as_float(aw[j] & 0xffff0000u) - x1;
+                    e += d0 * d0; e += d1 * d1; q += x0 * x0; q += x1 * x1;
+                }
+            }
+        }
+    } else {
+        for (int p = threadIdx.x; p < P; p += 1024) {
+            const float xv = Elem<T>::load(x, base + p);
+            const float dv = Elem<T>::load(adv, base + p) - xv;
+            e += dv * dv;
+            q += xv * xv;
+        }
     }
     e = wave_sum(e); q = wave_sum(q);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = e; red[1][threadIdx.x >> 6] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        sq_err[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        sq_norm[blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        float se = 0.0f, sn = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { se += red[0][w]; sn += red[1][w]; }
+        sq_err[blockIdx.x] = se;
+        sq_norm[blockIdx.x] = sn;
     }
 }
 
@@ -640,14 +668,19 @@ extern "C" int adil_image_metrics(const void* adv, const void* x, int B, int P, 
                                   float* sq_norm, void* stream) {
     ADIL_ENTER();
     if (!adv || !x || !sq_err || !sq_norm || B <= 0 || P <= 0) return ADIL_EINVAL;
-    if (dtype == ADIL_F32)
-        hipLaunchKernelGGL(image_metrics_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)adv,
-                           (const float*)x, P, sq_err, sq_norm);
-    else if (dtype == ADIL_BF16)
-        hipLaunchKernelGGL(image_metrics_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)adv,
-                           (const bf16_t*)x, P, sq_err, sq_norm);
-    else
+    const int esz = dtype == ADIL_F32 ? 4 : 2;
+    // 16-byte loads: every image row must start on a 16-byte boundary and hold a whole number of vectors
+    const bool vec = (((uintptr_t)adv | (uintptr_t)x) % 16 == 0) && (((size_t)P * esz) % 16 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ADIL_F32) {
+        if (vec) hipLaunchKernelGGL((image_metrics_kernel<float, true>), dim3(B), dim3(1024), 0, st, (const float*)adv, (const float*)x, P, sq_err, sq_norm);
+        else hipLaunchKernelGGL((image_metrics_kernel<float, false>), dim3(B), dim3(1024), 0, st, (const float*)adv, (const float*)x, P, sq_err, sq_norm);
+    } else if (dtype == ADIL_BF16) {
+        if (vec) hipLaunchKernelGGL((image_metrics_kernel<bf16_t, true>), dim3(B), dim3(1024), 0, st, (const bf16_t*)adv, (const bf16_t*)x, P, sq_err, sq_norm);
+        else hipLaunchKernelGGL((image_metrics_kernel<bf16_t, false>), dim3(B), dim3(1024), 0, st, (const bf16_t*)adv, (const bf16_t*)x, P, sq_err, sq_norm);
+    } else {
         return ADIL_EINVAL;
+    }
     ADIL_CHECK_LAUNCH();
     return 0;
 }

@@ -370,13 +370,22 @@ def test_pack_codes_slot_table_round_trip():
     assert torch.equal(va, vb)
 
 
-def test_image_metrics():
+@pytest.mark.parametrize("shape,dt", [((9, 3, 31, 17), torch.float32), ((9, 3, 31, 17), torch.bfloat16),
+                                      ((16, 3, 224, 224), torch.float32), ((16, 3, 224, 224), torch.bfloat16),
+                                      ((5, 3, 8, 6), torch.bfloat16)])
+def test_image_metrics(shape, dt):
+    """Per-image sum (adv - x)^2 and sum x^2 (performance.py:249-266) against fp64 sums of the same (stream-rounded) values:
+    the 16-byte-load path (full-size images) and the element-wise path (odd sizes / rows that do not start on 16 bytes)."""
     gen = torch.Generator().manual_seed(6)
-    x = torch.rand(9, 3, 31, 17, generator=gen)
-    adv = (x + 0.05 * torch.randn(x.shape, generator=gen)).clamp(0, 1)
+    x = torch.rand(*shape, generator=gen).to(dt)
+    adv = (x.float() + 0.05 * torch.randn(shape, generator=gen)).clamp(0, 1).to(dt)
     se, sn = ops().image_metrics(adv.to(DEV), x.to(DEV))
-    close(se, ((adv - x).double() ** 2).sum(dim=[1, 2, 3]), 1e-4)
-    close(sn, (x.double() ** 2).sum(dim=[1, 2, 3]), 1e-3)
+    ref_e = ((adv.double() - x.double()) ** 2).sum(dim=[1, 2, 3])
+    ref_n = (x.double() ** 2).sum(dim=[1, 2, 3])
+    close(se, ref_e, 2e-6 * float(ref_e.max()) + 1e-6)
+    close(sn, ref_n, 2e-6 * float(ref_n.max()) + 1e-6)
+    se2, sn2 = ops().image_metrics(adv.to(DEV), x.to(DEV))                        # bitwise reproducible
+    assert torch.equal(se, se2) and torch.equal(sn, sn2)
 
 
 def test_errors_are_loud():
