@@ -397,6 +397,27 @@ def test_errors_are_loud():
     with pytest.raises(TypeError):
         o.synth(torch.zeros(2, 3, 4, 4, device=DEV, dtype=torch.float16), torch.zeros(3, 4, 4, 2, device=DEV),
                 torch.zeros(32, 16, device=DEV), 2)
+    # ABI 6 arguments, straight through the C ABI: inconsistent slab descriptions are refused (ADIL_EINVAL = -1), never run
+    from ctypes import c_void_p
+    from dl_attack_on_imagenet_amd import _lib
+    lib = _lib.load()
+    v = torch.zeros(8, 4, device=DEV)
+    vp = torch.zeros(32, 16, device=DEV)
+    pos = torch.full((8,), -1, dtype=torch.int32, device=DEV)
+    slabs = torch.zeros(3 * 32 * 4, device=DEV)
+    P, st = (lambda t: c_void_p(0 if t is None else t.data_ptr())), c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.adil_pack_codes(P(None), P(None), 8, 4, P(vp), P(None), P(None), 0, P(None), 3, 32, st) == -1    # slabs announced, none given
+    assert lib.adil_pack_codes(P(None), P(None), 8, 4, P(vp), P(pos), P(None), 0, P(slabs), 3, 32, st) == -1   # slab source has no slot table
+    assert lib.adil_pack_codes(P(None), P(None), 8, 4, P(vp), P(None), P(None), 0, P(slabs), 3, 4, st) == -1    # fewer slab rows than batch rows
+    assert lib.adil_pack_codes(P(None), P(None), 8, 4, P(vp), P(None), P(None), 0, P(None), 0, 0, st) == -1     # neither v nor slabs
+    m, s_ = torch.zeros_like(v), torch.zeros_like(v)
+    args = (8, 4, 0.99, 0.9, 0.999, 1e-8, 0.1, 0.03, 0.5, P(None), P(None), 0.0, P(None), P(None))
+    assert lib.adil_adamw_l1ball(P(v), P(None), P(None), 0, P(m), P(s_), *args, P(None), 3, 32, st) == -1        # nslabs without slabs
+    assert lib.adil_adamw_l1ball(P(v), P(None), P(None), 0, P(m), P(s_), *args, P(slabs), 3, 4, st) == -1        # no slot table: one slab row per code row
+    assert lib.adil_adamw_l1ball(P(v), P(None), P(None), 0, P(m), P(s_), *args, P(None), 0, 0, st) == -1         # no gradient source at all
+    assert lib.adil_atom_l1ball_project(P(None), 3, 16, 4, 1.0, st) == -1
+    assert lib.adil_grad_code_rows(0) == 0 and lib.adil_grad_code_rows(50) == 64 and lib.adil_grad_code_rows(100) == 128
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
