@@ -400,6 +400,8 @@ def bench_transfer(args, rank, world, dev, timer):
         "kernels_ms_per_launch": kern_ms, "kernel_launches_timed": launches,
         "dictionary_path_ms_per_step": sum(kern_ms[k] * launches[k] for k in kern_ms) / args.steps,
     }
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)                        # the synthetic dictionary file (60 MB at 100 atoms)
     if rank == 0 and world == 1 and args.cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_transfer(args, shape)
     return out
