@@ -8,7 +8,8 @@ run-to-run backward noise — which used to sit inside the comparison because ea
 is gone.  Three checks per step, each isolating one kernel group:
 
   synth     x + D v                          HIP vs oracle (fp32: absolute; bf16 streams: one bf16 ulp of the result + fp32 accumulation noise)
-  gradient  grad_d = g^T V, grad_v = g D     HIP vs oracle on the identical g, relative to the largest entry
+  gradient  grad_d = g^T V, grad_v = g D     HIP vs the fp64 evaluation of the oracle's contraction on the identical g,
+                                             relative to the largest entry
   update    AdamW + clamp / + l1 projection  HIP kernels fed the ORACLE's gradient vs the oracle's update: identical inputs,
                                              so any difference is the update kernels' own arithmetic
 and the composite (HIP gradient -> HIP update vs oracle gradient -> oracle update), which additionally contains AdamW's
@@ -82,12 +83,14 @@ def shared_gradient_step(O, engine, model, learner, twin, x_stream, index, label
         t_h, t_o = out.float().topk(2, dim=1).values, out_o.topk(2, dim=1).values
         differ_margin = float(torch.minimum(t_h[:, 0] - t_h[:, 1], t_o[:, 0] - t_o[:, 1])[differ].max())
     # (3) the gradient contractions on the SAME g
-    gd_o, gv_o = O.grad_dv(g.float(), dop, vop)
+    gd_o, gv_o = O.grad_dv(g.float(), dop, vop)                    # the oracle's own fp32 contraction (feeds its update)
+    gd_x, gv_x = O.grad_dv(g.double(), dop.double(), vop.double())  # ... and the exact one the kernels are measured against
     gd_h, gvb = learner.backward(g, codes)
     gv_h = ops.pack_codes(gvb, None, b)[:b, :k] if isinstance(gvb, ops.SlabGrad) else gvb
-    e_gd = float((gd_h - gd_o).abs().max() / gd_o.abs().max().clamp_min(1e-30))
-    e_gv = float((gv_h - gv_o).abs().max() / gv_o.abs().max().clamp_min(1e-30))
+    e_gd = float((gd_h.double() - gd_x).abs().max() / gd_x.abs().max().clamp_min(1e-30))
+    e_gv = float((gv_h.double() - gv_x).abs().max() / gv_x.abs().max().clamp_min(1e-30))
     abs_gd = float((gd_h - gd_o).abs().max())
+    del gd_x, gv_x
     # (4) the update kernels on the ORACLE's gradient (twin) and the product's full step (learner)
     twin.synthesize(x_stream, index)                               # fills the batch-slot table update_v consumes
     twin.update_v(gv_o.contiguous())
