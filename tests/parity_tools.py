@@ -122,4 +122,5 @@ def worst_of(records, skip=("fooled", "fooled_on_oracle_synth", "loss", "frac_we
     if records and records[0].get("synth_worst") is not None:
         out["synth_worst_element"] = max((r["synth_worst"] for r in records), key=lambda w: w["ratio"])
     out["frac_well_conditioned_min"] = min(r["frac_well_conditioned"] for r in records)
+    out["contraction_reference"] = "fp64"          # (marker for tests/parity_report.py: earlier runs compared with the fp32 GEMM)
     return out

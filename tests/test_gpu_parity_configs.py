@@ -109,7 +109,7 @@ def _assert_kernel_bounds(w, bf16):
         assert w["synth"] <= 1.0, w                       # one bf16 ulp of the result + fp32 accumulation noise (parity_tools)
     else:
         assert w["synth"] <= 1e-5, w                      # fp32: absolute on O(1) pixels (measured 3e-7 ... 6e-7)
-    assert w["grad_d_rel"] <= 1e-5 and w["grad_v_rel"] <= 1e-5, w          # contractions on the identical g
+    assert w["grad_d_rel"] <= 2e-6 and w["grad_v_rel"] <= 2e-6, w          # contractions on the identical g vs their fp64 evaluation (measured 1e-7 ... 6e-7)
     assert w["update_dD"] <= 1e-6 and w["update_dV"] <= 1e-6, w            # update kernels on the identical gradient
     assert w["dV"] <= 1e-5, w                                               # composite, codes
     assert w["dD_well_conditioned"] <= 1e-5, w                              # composite, dictionary, sqrt(v_hat) >= 1e-6
@@ -120,7 +120,7 @@ def _assert_kernel_bounds(w, bf16):
 def test_config1_shared_gradient_steps_fp32():
     """configs[0]: resnet18, 32 images, 10 atoms, 20 iterations, fp32, loss 'logits' — 20 teacher-forced steps along the
     oracle's trajectory, ONE classifier evaluation per step shared by both sides.  Asserted at every step: synthesis
-    <= 1e-5, both gradient contractions <= 1e-5 relative, update kernels on the identical gradient <= 1e-6, composite
+    <= 1e-5, both gradient contractions <= 2e-6 relative to their fp64 evaluation, update kernels on the identical gradient <= 1e-6, composite
     |dV| <= 1e-5, composite |dD| <= 1e-5 on the well-conditioned entries and below AdamW's amplification bound
     everywhere; the argmax label decisions on the product's and on the oracle's synthesised batch EQUAL at all 20 points."""
     from dl_attack_on_imagenet_amd import engine, zoo
