@@ -20,7 +20,9 @@ runs = [[json.loads(line) for line in open(path)] for path in sys.argv[1:]]
 if len(runs) > 1:
     print(f"## Run-to-run spread over {len(runs)} runs (separate processes / boxes of the pool)\n")
     print("Every figure below was under its asserted bound in every run (all runs green); min … max over the runs.\n")
-    names = [j["test"] for j in runs[0]]
+    names = []
+    for run in runs:
+        names += [j["test"] for j in run if j["test"] not in names]
     for name in names:
         recs = [j for run in runs for j in run if j["test"] == name]
         if recs and "worst" in recs[0]:
@@ -33,12 +35,14 @@ if len(runs) > 1:
             print("| " + " | ".join(f"{fmt(float(min(r['worst'][k] for r in recs)))} … {fmt(float(max(r['worst'][k] for r in recs)))}" for k in keys) + " |\n")
         elif name == "asr_parity_structured":
             print("**asr_parity_structured** (ASR through the reference's pipeline on held-out structured images)\n")
-            print("| run | held-out images | ASR A (fp32 reference configuration) | ASR C (bf16 product) | fp32 inference of the other side with C's dictionary | \\|A − C\\| |\n|---|---|---|---|---|---|")
+            print("| run | held-out images | ASR A (fp32 reference configuration) | ASR C (bf16 product) | oracle fp32 inference with C's dictionary | PRODUCT fp32 inference with C's dictionary | \\|A − C\\| |\n|---|---|---|---|---|---|---|")
             for i, r in enumerate(recs):
                 a, c = r["asr_A"], r["asr_C"]
                 x = r["asr_oracle_inference_fp32_net_with_the_products_dictionary"]
                 nx = r.get("cross_check_images", r.get("samples", 512))
-                print(f"| {i + 1} | {r.get('samples', 512)} | {100 * a:.2f} % | {100 * c:.2f} % | {100 * x:.2f} % (of {nx}) | {100 * abs(a - c):.2f} pp |")
+                p32 = r.get("asr_product_inference_fp32_streams_fp32_net_with_the_products_dictionary")
+                p32 = f"{100 * p32:.2f} %" if p32 is not None else "—"
+                print(f"| {i + 1} | {r.get('samples', 512)} | {100 * a:.2f} % | {100 * c:.2f} % | {100 * x:.2f} % (of {nx}) | {p32} | {100 * abs(a - c):.2f} pp |")
             print()
 for path in sys.argv[1:]:
     print(f"## run `{path.split('/')[-1]}`\n")
