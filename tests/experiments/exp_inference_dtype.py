@@ -36,7 +36,10 @@ ds = torch.utils.data.TensorDataset(held, held_labels)
 out = {}
 batches = [(held[lo:lo + 128].to(dev), held_labels[lo:lo + 128].to(dev)) for lo in range(0, 1024, 128)]
 out["oracle inference, fp32 streams, fp32 net"] = O.performance(lambda xx, yy: O.forward_supervised_ddrague(ref, xx, learner.d, eps, S, "logits"), ref, batches)["fooling_rate"]
+from dl_attack_on_imagenet_amd import zoo
+plain16 = zoo.build_classifier("resnet50", seed=0, weights=os.path.join(tmp, "resnet50_fitted.pt"), device=dev, dtype=torch.bfloat16)
 for tag, model, sdt in (("product inference, fp32 streams, fp32 net", ref, None),
+                        ("product inference, bf16 streams, PLAIN PyTorch bf16 net (no kernels of this repo in the classifier)", plain16, torch.bfloat16),
                         ("product inference, fp32 streams, bf16 net behind an fp32 interface", AsFp32(fast), None),
                         ("product inference, bf16 streams, bf16 net (configs[1])", fast, torch.bfloat16)):
     atk = ADIL(model, eps=eps, n_atoms=k, attack="supervised", model_name="x", loss="logits", steps_inference=S, dict_dir=tmp, stream_dtype=sdt)
