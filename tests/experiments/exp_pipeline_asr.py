@@ -49,6 +49,15 @@ t0 = time.time()
 res = loader.ResidentBatches(ds, held_labels, 128, dev, torch.bfloat16)
 pc = perf.performance(atk, fast, res)
 out["eval_C_s"] = time.time() - t0
+# leg P (LEG_P=1): the product in the REFERENCE's configuration — fp32 streams, the fp32 network — end to end
+if E("LEG_P", "0") == "1":
+    lp = engine.DictionaryLearner(d0.clone().to(dev), v0.clone().to(dev), eps, 0.01, "logits", False, 50.0)
+    lab32 = engine.predict(ref, x32)
+    fp = [int(lp.step(ref, x32, index, lab32)[1]) for _ in range(T)]
+    torch.save([lp.d.cpu(), lp.v.cpu(), [], [], torch.tensor(0.)], os.path.join(tmp, "ImageNet_p.bin"))
+    atkp = ADIL(ref, eps=eps, n_atoms=k, attack="supervised", model_name="p", loss="logits", steps_inference=S, dict_dir=tmp)
+    out["perf_P_product_fp32_end_to_end"] = {kk: float(vv) for kk, vv in perf.performance(atkp, ref, loader.ResidentBatches(ds, held_labels, 128, dev)).items()}
+    out["fooled_learn_P"] = fp[::10] + [fp[-1]]
 # cross: the product's dictionary attacked by the oracle inference on the fp32 net, and vice versa
 pca = O.performance(lambda xx, yy: O.forward_supervised_ddrague(ref, xx, learner.d, eps, S, "logits"), ref, batches)
 out.update(fooled_learn_A=fa[::10] + [fa[-1]], fooled_learn_C=fc[::10] + [fc[-1]], perf_A=pa, perf_C=pc, perf_oracle_inference_with_product_D=pca)
