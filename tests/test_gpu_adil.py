@@ -918,3 +918,34 @@ def test_bench_transfer_mode_line(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["config"]["collective"]["backend"] == "gloo"
     assert abs(line["value"] - 2 * 4 * 1 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+
+
+def test_bench_inference_and_learn_mode_lines(tmp_path):
+    """`bench.py --mode inference` and the default learn mode at a plumbing size: one JSON line each with the contract's keys;
+    the learn line carries BOTH pseudo-label policies at the top level (`value` = cached labels by default, the reference's
+    recomputing sequence next to it) and `--cache-labels 0` swaps them."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--model", "resnet18", "--batch", "8", "--atoms", "10", "--steps", "3", "--warmup", "1", "--cpu-baseline", "0"]
+
+    def line(*extra):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common + list(extra), capture_output=True, text=True,
+                           timeout=600, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    inf = line("--mode", "inference")
+    assert inf["roofline"]["kernel"] == "zstep_" and inf["unit"] == "images/sec" and inf["n_gpus"] == 1 and inf["steps"] == 3
+    assert set(inf["kernels_ms_per_step"]) >= {"grad[z D_dagger^T]", "synth", "grad", "zstep_", "pack_codes"}
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in inf["roofline"]
+    learn = line()
+    assert "cached" in learn["config"]["workload"] and learn["value_cached_labels"] == learn["value"]
+    assert learn["value_reference_op_sequence_recomputed_labels"] == learn["config"]["recomputed_labels_variant"]["images_per_sec"]
+    assert learn["config"]["collective"]["world_size"] == 1 and learn["config"]["collective"]["backend"] is None
+    ref = line("--cache-labels", "0")
+    assert "recomputed" in ref["config"]["workload"] and ref["value_reference_op_sequence_recomputed_labels"] == ref["value"]
+    assert ref["value_cached_labels"] == ref["config"]["cached_labels_variant"]["images_per_sec"]
