@@ -33,6 +33,11 @@ def build_parser():
     p.add_argument('--weights', default=None, help='local torchvision state_dict for the classifier')
     p.add_argument('--synthetic', action='store_true', help='use a seeded synthetic dataset (no ILSVRC files needed)')
     p.add_argument('--synthetic-classes', type=int, default=10)
+    p.add_argument('--synthetic-structured', type=int, default=1,
+                   help='--synthetic: 1 (default) = class-structured images (imagenet_loading.SyntheticImageNet(structured=True)) and '
+                        'the classifier\'s last layer fitted to the training split in closed form (zoo.fit_centroid_head), so that the '
+                        'pipeline reports real fooling rates without pretrained weights; 0 = U[0,1) noise images, random-init head '
+                        '(performance.py\'s correctly-classified filter then keeps next to nothing)')
     p.add_argument('--image-size', type=int, default=224)
     p.add_argument('--n-atoms', type=int, default=100)
     p.add_argument('--steps', type=int, default=500)
@@ -89,17 +94,23 @@ def main(args):
     model_name = args.model.lower()          # names the dictionary file, as upstream (demo_dL_attack.py:41, adil.py:89-91)
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     fast = bool(args.fast_classifier) and dtype == torch.bfloat16 and zoo.canonical_name(model_name).startswith('resnet')
-    model = zoo.build_classifier(model_name, seed=args.seed, weights=args.weights, device=device, dtype=dtype,
-                                 channels_last=fast, fuse_bn_act=fast, fuse_stem=fast)
 
+    structured = bool(args.synthetic and args.synthetic_structured)
     if args.synthetic:
-        dataset = SyntheticImageNet(num_classes=args.synthetic_classes, size=args.image_size, seed=args.seed)
+        dataset = SyntheticImageNet(num_classes=args.synthetic_classes, size=args.image_size, seed=args.seed,
+                                    structured=structured)
         n_classes = min(args.trained_classes, args.synthetic_classes)
     else:
         dataset, _ = load_ImageNet()
         n_classes = args.trained_classes
     train_dataset, val_dataset, test_dataset = dataset_split_by_class(
         dataset, [args.num_train_per_class, 2, 5], number_of_classes=n_classes)         # demo_dL_attack.py:69-78
+
+    weights = args.weights
+    if structured and weights is None:
+        weights = _fitted_weights(model_name, args.seed, train_dataset, n_classes, device)
+    model = zoo.build_classifier(model_name, seed=args.seed, weights=weights, device=device, dtype=dtype,
+                                 channels_last=fast, fuse_bn_act=fast, fuse_stem=fast)
     val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=10, shuffle=False)
     test_loader = torch.utils.data.DataLoader(test_dataset, batch_size=20, shuffle=False)
 
@@ -127,6 +138,23 @@ def main(args):
     if writer:                                                                            # demo_dL_attack.py:153-156
         torch.save(test_perf, os.path.join(out_dir, 'model_adil_resultat_test_ce.bin'))
     return val_perf, test_perf
+
+
+def _fitted_weights(model_name, seed, train_dataset, n_classes, device):
+    """No pretrained weights offline: fit the last layer of the seeded random-weight network to the structured training
+    split (zoo.fit_centroid_head, closed form) and hand the result to build_classifier as a local state_dict — the same
+    route a torchvision checkpoint takes.  Every rank of a --distributed run computes the same file content."""
+    import tempfile
+    plain = zoo.build_classifier(model_name, seed=seed, device=device)
+    train_dataset.indexed = False
+    images = torch.stack([train_dataset[i][0] for i in range(len(train_dataset))])
+    labels = torch.tensor([int(train_dataset[i][1]) for i in range(len(train_dataset))])
+    margins, pred = zoo.fit_centroid_head(plain, images, labels, n_classes, device)
+    print(f'fitted the classifier head to {len(labels)} structured training images: accuracy '
+          f'{float((pred == labels).float().mean()):.3f}, median clean margin {float(margins.median()):.1f}')
+    path = os.path.join(tempfile.mkdtemp(prefix='adil_demo_'), f'{model_name}_fitted.pt')
+    torch.save(plain[-1].state_dict(), path)
+    return path
 
 
 class _CastLoader:

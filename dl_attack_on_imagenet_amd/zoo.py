@@ -784,6 +784,46 @@ class FusedResNet(nn.Module):
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 
+@torch.no_grad()
+def fit_centroid_head(model: nn.Module, images: torch.Tensor, labels: torch.Tensor, classes: int, device,
+                      target_margin: float = 10.0, chunk: int = 64):
+    """Overwrite the last linear layer of `model` (Sequential(Normalize, net) from build_classifier, fp32, plain modules)
+    with the nearest-centroid classifier of its own penultimate features on (images, labels):
+    logit_c = s * (z . m_c - |m_c|^2 / 2), z = standardised feature, m_c = class mean; s scales the median clean margin to
+    `target_margin`.  The other output classes get weight 0 and a large negative bias.  Closed form, seeded by its inputs,
+    a few seconds: it gives a random-weight backbone a head that separates a structured synthetic dataset
+    (imagenet_loading.SyntheticImageNet(structured=True)) with margins far above bf16 rounding, which is what the offline
+    demo and the ASR-parity tests need (there are no pretrained weights on a box without network).
+    Returns (clean top-2 margins, predicted labels) of the fitted network on the images."""
+    net = model[-1]
+    fc = net.fc if hasattr(net, "fc") else (net.classifier if hasattr(net, "classifier") else net.heads.head)
+    if isinstance(fc, nn.Sequential):
+        fc = fc[-1]
+    if not isinstance(fc, nn.Linear):
+        raise TypeError("fit_centroid_head: the network's last layer must be a Linear")
+    feats = []
+    hook = fc.register_forward_pre_hook(lambda m, a: feats.append(a[0].detach().double().cpu()))
+    for part in images.split(chunk):
+        model(part.to(device))
+    hook.remove()
+    f = torch.cat(feats)
+    mu, sd = f.mean(0), f.std(0) + 1e-6 * f.std(0).max()
+    z = (f - mu) / sd
+    means = torch.stack([z[labels == c].mean(0) for c in range(classes)])           # (C, F)
+    logits = z @ means.t() - 0.5 * (means * means).sum(1)
+    top2 = logits.topk(2, dim=1).values
+    s = target_margin / float((top2[:, 0] - top2[:, 1]).median())
+    w = s * means / sd                                                                # (C, F) on raw features
+    b = s * (-(means * (mu / sd)).sum(1) - 0.5 * (means * means).sum(1))
+    fc.weight.zero_()
+    fc.bias.fill_(-1.0e4)
+    fc.weight[:classes] = w.to(fc.weight)
+    fc.bias[:classes] = b.to(fc.bias)
+    out = torch.cat([model(part.to(device)).double().cpu() for part in images.split(chunk)])
+    top2 = out.topk(2, dim=1).values
+    return top2[:, 0] - top2[:, 1], out.argmax(1)
+
+
 def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights: Optional[str] = None,
                      device=None, dtype: torch.dtype = torch.float32, channels_last: bool = False,
                      fold_bn: bool = False, pad_input_channels: int = 0, fuse_bn_act: bool = False,

@@ -49,16 +49,33 @@ def load_ImageNet(imagenet_file='./data/ImageNet/ImageNet1000_unnormalized.bin')
 
 
 class SyntheticImageNet(Dataset):
-    """Seeded U[0,1) images (3,size,size) with the `.samples` / `.classes` attributes the split relies on."""
+    """Seeded synthetic images (3,size,size) in [0,1] with the `.samples` / `.classes` attributes the split relies on.
 
-    def __init__(self, num_classes=10, samples_per_class=50, size=224, seed=0):
+    structured=False: U[0,1) noise with arbitrary labels — the shape of the data, nothing to classify (a classifier is
+    right on ~1/num_classes of it, so performance.py's correctly-classified filter keeps next to nothing).
+    structured=True: class c = a coarse `cells` x `cells` colour pattern (fixed by `seed`), bilinearly upsampled, plus
+    per-pixel Gaussian noise — images a classifier CAN separate (zoo.fit_centroid_head fits the last layer of a
+    random-weight network to them in closed form), so that the whole pipeline — learn, attack, evaluate — reports real
+    fooling rates on a box without the ILSVRC files."""
+
+    def __init__(self, num_classes=10, samples_per_class=50, size=224, seed=0, structured=False, noise=0.10, cells=7):
         self.classes = [f"class_{i}" for i in range(num_classes)]
         self.samples = [(f"synthetic_{i}", i // samples_per_class) for i in range(num_classes * samples_per_class)]
-        self.size, self.seed = size, seed
+        self.size, self.seed, self.structured, self.noise = size, seed, bool(structured), float(noise)
+        self.prototypes = None
+        if self.structured:
+            g = torch.Generator().manual_seed(seed)
+            protos = torch.rand(num_classes, 3, cells, cells, generator=g)
+            self.prototypes = torch.nn.functional.interpolate(protos, size=(size, size), mode="bilinear",
+                                                              align_corners=False) * 0.6 + 0.2
 
     def __len__(self):
         return len(self.samples)
 
     def __getitem__(self, item):
         g = torch.Generator().manual_seed(self.seed * 1_000_003 + int(item))
-        return torch.rand(3, self.size, self.size, generator=g), self.samples[item][1]
+        label = self.samples[item][1]
+        if not self.structured:
+            return torch.rand(3, self.size, self.size, generator=g), label
+        x = self.prototypes[label] + self.noise * torch.randn(3, self.size, self.size, generator=g)
+        return x.clamp_(0.0, 1.0), label

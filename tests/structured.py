@@ -26,38 +26,10 @@ def structured_images(n, classes=10, seed=0, size=224, noise=0.10, cells=7, draw
     return images, labels
 
 
-@torch.no_grad()
 def fit_centroid_head(model, images, labels, classes, device, target_margin=10.0, chunk=64):
-    """Overwrite the last linear layer of `model` (Sequential(Normalize, net) from zoo.build_classifier, fp32, plain
-    modules) with the nearest-centroid classifier of its own penultimate features on (images, labels):
-    logit_c = s * (z . m_c - |m_c|^2 / 2), z = standardised feature, m_c = class mean; s scales the median clean
-    margin to `target_margin`.  The other output classes get weight 0 and a large negative bias.  Returns the clean
-    logit margins of the fitted network on the images."""
-    net = model[-1]
-    fc = net.fc if hasattr(net, "fc") else (net.classifier if hasattr(net, "classifier") else net.heads.head)
-    if not isinstance(fc, torch.nn.Linear):
-        raise TypeError("fit_centroid_head: the network's last layer must be a Linear")
-    feats = []
-    hook = fc.register_forward_pre_hook(lambda m, a: feats.append(a[0].detach().double().cpu()))
-    for part in images.split(chunk):
-        model(part.to(device))
-    hook.remove()
-    f = torch.cat(feats)
-    mu, sd = f.mean(0), f.std(0) + 1e-6 * f.std(0).max()
-    z = (f - mu) / sd
-    means = torch.stack([z[labels == c].mean(0) for c in range(classes)])           # (C, F)
-    logits = z @ means.t() - 0.5 * (means * means).sum(1)
-    top2 = logits.topk(2, dim=1).values
-    s = target_margin / float((top2[:, 0] - top2[:, 1]).median())
-    w = s * means / sd                                                                # (C, F) on raw features
-    b = s * (-(means * (mu / sd)).sum(1) - 0.5 * (means * means).sum(1))
-    fc.weight.zero_()
-    fc.bias.fill_(-1.0e4)
-    fc.weight[:classes] = w.to(fc.weight)
-    fc.bias[:classes] = b.to(fc.bias)
-    out = torch.cat([model(part.to(device)).double().cpu() for part in images.split(chunk)])
-    top2 = out.topk(2, dim=1).values
-    return top2[:, 0] - top2[:, 1], out.argmax(1)
+    """The product's closed-form head fit (zoo.fit_centroid_head; it also serves `demo_dL_attack.py --synthetic`)."""
+    from dl_attack_on_imagenet_amd import zoo
+    return zoo.fit_centroid_head(model, images, labels, classes, device, target_margin=target_margin, chunk=chunk)
 
 
 def fitted_classifiers(name, images, labels, classes, device, tmp_dir, seed=0, target_margin=10.0):

@@ -369,3 +369,19 @@ def test_bench_defaults_by_mode_and_traffic_is_tied_to_the_build(tmp_path, monke
     assert bench.measured_traffic("synth", 50) is None
     a50 = bench.algorithmic_bytes(512, 150528, 50, 512, 2, "learn")
     assert a50["synth"] == 2 * 512 * 150528 * 2 + 150528 * 50 * 4 + 512 * 50 * 4          # 338.5 MB
+
+
+def test_structured_synthetic_dataset_is_seeded_and_separable():
+    """imagenet_loading.SyntheticImageNet(structured=True): deterministic items, images of one class closer to each other than
+    to another class, the `.samples` / `.classes` attributes of the split; structured=False stays the U[0,1) stand-in."""
+    from imagenet_loading import SyntheticImageNet
+    ds = SyntheticImageNet(num_classes=3, samples_per_class=50, size=32, seed=2, structured=True)
+    x0, y0 = ds[0]
+    x0b, _ = ds[0]
+    x1, y1 = ds[1]
+    x50, y50 = ds[50]
+    assert torch.equal(x0, x0b) and (y0, y1, y50) == (0, 0, 1) and x0.shape == (3, 32, 32)
+    assert float(x0.min()) >= 0.0 and float(x0.max()) <= 1.0
+    assert float((x0 - x1).abs().mean()) < float((x0 - x50).abs().mean())
+    flat = SyntheticImageNet(num_classes=3, samples_per_class=50, size=32, seed=2)
+    assert flat.prototypes is None and not torch.equal(flat[0][0], x0)
