@@ -407,3 +407,42 @@ def test_other_classifiers_learner_step_at_bench_size(name, k):
     assert torch.isfinite(learner.d).all() and torch.isfinite(learner.v).all()
     assert float(learner.d.abs().max()) <= 1.0 and float(learner.v.abs().sum(1).max()) <= EPS * (1 + 1e-5)
     assert all(0 <= f <= n for f in fooled)
+
+
+def test_transfer_evaluation_parity_at_real_size(tmp_path):
+    """configs[3] at real image size (golden G15 pins it on tiny networks): `performance.get_transfer_performance` of the product —
+    resident evaluation set, ADIL.forward with 100 DDrague iterations against the fp32 ResNet-50, the adversary scored on
+    the six classifiers of the reference CLI — against the oracle's `transfer_performance` (performance.py:205-232 restated)
+    on the same dictionary, 128 held-out structured images, every network with a fitted head.  Fooling rate per target
+    within one image of 128 (measured: identical, incl. the few images that transfer at all), rmse / mse within 1e-3 relative."""
+    import performance as perf
+    from attacks import ADIL
+    from dl_attack_on_imagenet_amd import engine, loader, zoo
+    from oracle import adil_oracle as O
+    from structured import fitted_classifiers, structured_images
+    n, k, T, S = 128, 50, 100, 100
+    images, labels = structured_images(n, 10, seed=3)
+    held, held_labels = structured_images(n, 10, seed=3, draw=1)
+    ref, fast, _, _ = fitted_classifiers("resnet50", images, labels, 10, DEV, tmp_path)
+    targets = {}
+    for name in ("resnet18", "densenet121", "googlenet", "inception_v3", "mobilenet_v2", "vgg11"):
+        targets[name] = zoo.build_classifier(name, seed=1, device=DEV)
+        _, pred = zoo.fit_centroid_head(targets[name], images, labels, 10, DEV)
+        assert bool((pred == labels).all()), name
+    g = torch.Generator().manual_seed(33)
+    d0 = -1 + 2 * torch.rand(3, 224, 224, k, generator=g)
+    v0 = O.project_onto_l1_ball(torch.rand(n, k, generator=g), EPS)
+    dc, vc, _, _ = _hip_run(engine, fast, images, d0, v0, T, EPS, [list(range(n))], dtype=torch.bfloat16)
+    torch.save([dc.cpu(), vc.cpu(), [], [], torch.tensor(0.)], os.path.join(tmp_path, "ImageNet_transfer.bin"))
+    batches = [(held[lo:lo + 64].to(DEV), held_labels[lo:lo + 64].to(DEV)) for lo in range(0, n, 64)]
+    po = O.transfer_performance(lambda xx, yy: O.forward_supervised_ddrague(ref, xx, dc, EPS, S, "logits"), targets, batches, n)
+    atk = ADIL(ref, eps=EPS, n_atoms=k, attack="supervised", model_name="transfer", loss="logits", steps_inference=S,
+               dict_dir=str(tmp_path))
+    res = loader.ResidentBatches(torch.utils.data.TensorDataset(held, held_labels), held_labels, 64, DEV)
+    pp = perf.get_transfer_performance({"adil": [atk]}, targets, res, device=torch.device(DEV))["adil"]
+    _note("transfer_parity_real_size", {name: dict(oracle=po[name], product={kk: float(vv) for kk, vv in pp[name].items()})
+                                        for name in targets})
+    for name in targets:
+        assert abs(po[name]["fooling_rate"] - float(pp[name]["fooling_rate"])) <= 1.0 / n + 1e-9, (name, po[name], pp[name])
+        for key in ("rmse", "mse"):
+            assert abs(po[name][key] - float(pp[name][key])) <= 1e-3 * abs(po[name][key]), (name, key, po[name], pp[name])
