@@ -44,7 +44,9 @@ if len(runs) > 1:
                 p32 = f"{100 * p32:.2f} %" if p32 is not None else "—"
                 print(f"| {i + 1} | {r.get('samples', 512)} | {100 * a:.2f} % | {100 * c:.2f} % | {100 * x:.2f} % (of {nx}) | {p32} | {100 * abs(a - c):.2f} pp |")
             print()
-for path in sys.argv[1:]:
+if len(sys.argv) > 3:
+    print(f"(Per-run details below: the two most recent of the {len(sys.argv) - 1} runs; the others enter the spread above.)\n")
+for path in sys.argv[1:][-2:]:
     print(f"## run `{path.split('/')[-1]}`\n")
     for line in open(path):
         j = json.loads(line)
