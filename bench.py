@@ -65,7 +65,8 @@ def parse_args():
     p.add_argument("--fp8-synth", type=int, default=0,
                    help="1: the D.V contraction of the synthesis on fp8 (e4m3) MFMAs (BASELINE.json configs[4]); learn mode")
     p.add_argument("--cpu-baseline", type=int, default=1)
-    p.add_argument("--cpu-batch", type=int, default=32, help="images of the config-2-shape CPU sample")
+    p.add_argument("--cpu-batch", type=int, default=64, help="images of the config-2-shape CPU sample (64 images x 1 step: ~15-20 s "
+                                                             "on the box's host cores)")
     p.add_argument("--cpu-steps", type=int, default=1)
     p.add_argument("--cpu-config1", type=int, default=1, help="also run configs[0] (resnet18, 32 images, 10 atoms, 20 "
                                                               "iterations, fp32) in full on the host cores and on the GPU")
