@@ -958,3 +958,19 @@ def test_bench_inference_and_learn_mode_lines(tmp_path):
     ref = line("--cache-labels", "0")
     assert "recomputed" in ref["config"]["workload"] and ref["value_reference_op_sequence_recomputed_labels"] == ref["value"]
     assert ref["value_cached_labels"] == ref["config"]["cached_labels_variant"]["images_per_sec"]
+
+
+def test_resident_images_upload_through_worker_processes():
+    """loader.ResidentImages(num_workers=2): the items fetched by DataLoader worker processes (what a JPEG-decoding dataset
+    needs for its one-time upload) give the same resident tensor as the in-process fetch — all rows and a row subset,
+    with and without the `indexed` protocol switched on."""
+    from dl_attack_on_imagenet_amd import loader
+    g = torch.Generator().manual_seed(8)
+    ds = IndexedTensorDataset(torch.rand(37, 3, 16, 16, generator=g))
+    ds.indexed = True
+    a = loader.ResidentImages(ds, DEV, torch.bfloat16, chunk=8)
+    b = loader.ResidentImages(ds, DEV, torch.bfloat16, chunk=8, num_workers=2)
+    assert ds.indexed is True and torch.equal(a.images, b.images) and torch.equal(a.images.float().cpu(), ds.images.to(torch.bfloat16).float())
+    rows = [5, 0, 36, 7, 7, 20]
+    c = loader.ResidentImages(ds, DEV, torch.float32, rows=rows, chunk=4, num_workers=2)
+    assert torch.equal(c.images.cpu(), ds.images[rows])
