@@ -50,6 +50,8 @@ def build_parser():
                         '(one classifier forward less per learning step; measured result-neutral); 0 = the reference op sequence')
     p.add_argument('--val-every', type=int, default=1,
                    help='validate every this many epochs (0 = after the last epoch only); the dictionary file is the same')
+    p.add_argument('--upload-workers', type=int, default=0,
+                   help='worker processes fetching the dataset items for the one-time upload into HBM (JPEG decoding)')
     p.add_argument('--fast-classifier', type=int, default=1,
                    help='bf16 ResNets: run the frozen classifier on the hand-written stem / pointwise / 3x3 kernels '
                         '(zoo.FusedResNet, same function up to bf16 rounding); 0 = plain PyTorch modules')
@@ -122,7 +124,8 @@ def main(args):
                               is_distributed=args.distributed, steps_in=1, loss=args.loss, method=args.method,
                               data_val=val_dataset, warm_start=False, steps_inference=args.steps_inference,
                               stream_dtype=dtype if dtype != torch.float32 else None,
-                              cache_labels=bool(args.cache_labels), val_every=args.val_every),
+                              cache_labels=bool(args.cache_labels), val_every=args.val_every,
+                              upload_workers=args.upload_workers),
     }
     out_dir = 'dict_model_ImageNet_version_constrained'
     os.makedirs(out_dir, exist_ok=True)                                                   # quirk Q14: upstream assumes it exists

@@ -70,6 +70,8 @@ class ADIL(Attack):
       val_every      validate (100 AdamW iterations per validation batch, adil.py:199-205) every this many epochs; the
                      reference does it after EVERY epoch but only prints the value and stores the last one, so any
                      setting writes the same dictionary file; 0 = after the last epoch only.  Default 1 (as upstream)
+      upload_workers worker processes that fetch the dataset items for the one-time upload into HBM (loader.ResidentImages;
+                     0 = in-process, right for in-memory tensors; > 0 for datasets that decode a JPEG per item)
       use_graph      replay the learning step (engine.DictionaryLearner.step_graphed) and the DDrague inference iterations
                      (engine.DDragueSolver.run, three per launch) as hipGraph launches: for launch-bound uses — small
                      batches, the one-image attack of main.py; default: $ADIL_GRAPH == "1"
@@ -81,7 +83,8 @@ class ADIL(Attack):
                  data_train=None, data_val=None, trials=10, attack='supervised', model_name=None, step_size=0.01,
                  is_distributed=False, steps_in=None, loss='ce', method='gd', warm_start=False, kappa=50,
                  steps_inference=30, alpha=None, init_d=None, init_v=None, epoch_batches=None, val_batches=None,
-                 stream_dtype=None, dict_dir='trained_dicts', shuffle_seed=0, use_graph=None, cache_labels=True, val_every=1):
+                 stream_dtype=None, dict_dir='trained_dicts', shuffle_seed=0, use_graph=None, cache_labels=True, val_every=1,
+                 upload_workers=0):
         super().__init__("ADIL", model.eval())
         self.norm = norm.lower()
         self.eps = eps
@@ -106,6 +109,7 @@ class ADIL(Attack):
         self._use_graph = (os.environ.get("ADIL_GRAPH") == "1") if use_graph is None else bool(use_graph)
         self._cache_labels = bool(cache_labels)
         self._val_every = int(val_every)
+        self._upload_workers = int(upload_workers)
         self._pinv = None
         self._solvers = {}
         self._dict_mtime = None
@@ -157,7 +161,8 @@ class ADIL(Attack):
     def _resident(self, dataset, rows=None):
         """The data step in front of the path: the dataset (or this rank's rows of it) resident in HBM in the stream
         dtype; replaces the per-item DataLoader of adil.py:130-133 (see loader.py)."""
-        return ResidentImages(dataset, self.device, self.stream_dtype or torch.float32, rows=rows)
+        return ResidentImages(dataset, self.device, self.stream_dtype or torch.float32, rows=rows,
+                              num_workers=self._upload_workers)
 
     @staticmethod
     def _epoch_order(n, batch_size, explicit, epoch):
