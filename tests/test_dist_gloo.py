@@ -96,7 +96,7 @@ def _install_oracle_backend(O):
     class HostImages:
         """Interface of loader.ResidentImages on host tensors."""
 
-        def __init__(self, dataset, device, dtype=torch.float32, rows=None, chunk=256):
+        def __init__(self, dataset, device, dtype=torch.float32, rows=None, chunk=256, num_workers=0):
             dataset.indexed = False
             self.rows = list(range(len(dataset))) if rows is None else list(rows)
             self.images = torch.stack([dataset[r][0] for r in self.rows]) if self.rows else torch.zeros(0, 3, 16, 16)
