@@ -132,7 +132,7 @@ class DictGradReducer:
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.timing = bool(timing)               # bench.py: HIP-event bracket around every start -> wait
-        self._brackets, self._open, self.bytes_per_call = [], None, 0
+        self._brackets, self.bytes_per_call = [], 0
         self.saw_async_work = False              # the asynchronous (RCCL) branch of all_reduce_start has been taken
 
     # -- measurement (bench.py's config.collective) ------------------------------------------------------------------ #
@@ -151,7 +151,7 @@ class DictGradReducer:
         return out
 
     def reset_timing(self) -> None:
-        self._brackets, self._open = [], None
+        self._brackets = []
 
     def all_reduce_(self, grad_d: torch.Tensor) -> torch.Tensor:
         return all_reduce_(grad_d, dist.ReduceOp.SUM, self.group)
@@ -159,7 +159,8 @@ class DictGradReducer:
     def all_reduce_start(self, grad_d: torch.Tensor):
         """Start the step's collective and return a handle whose .wait() orders the CURRENT stream behind it (RCCL runs on
         its own stream): the caller puts the work that does not need the reduced gradient — AdamW + projection of the code
-        rows — between start and wait.  The gloo rehearsal path reduces synchronously and returns None."""
+        rows — between start and wait.  The gloo rehearsal path reduces synchronously (its handle's wait() only closes the
+        timing bracket)."""
         self.bytes_per_call = grad_d.numel() * grad_d.element_size()
         e0 = None
         if self.timing and grad_d.is_cuda:
