@@ -5,7 +5,7 @@
 # the kernel sources is written next to them and into hbm_traffic*.json (bench.py reports roofline.traffic only for it).
 set -o pipefail
 tag=${1:-r03}
-phase=${2:-all}          # stats | pmc | lines | all   (one gpurun call holds 20 minutes: stats and pmc+lines fit one each)
+phase=${2:-all}          # stats | pmc | mfma | lines | all   (one gpurun call holds 20 minutes: stats and pmc+lines fit one each)
 root=$(pwd)
 export TMPDIR=/tmp
 out=$root/gpurun_out
@@ -42,6 +42,19 @@ K=50 python3 tools/pmc_traffic.py $out/pmc_${tag}_k50_FETCH_SIZE $out/pmc_${tag}
 K=100 python3 tools/pmc_traffic.py $out/pmc_${tag}_k100_FETCH_SIZE $out/pmc_${tag}_k100_WRITE_SIZE $out/${tag}_hbm_traffic_k100.json > $out/${tag}_hbm_traffic_k100.txt
 cp $out/${tag}_hbm_traffic.json profiles/hbm_traffic.json        # on the GPU box: the bench lines below then carry roofline.traffic
 cp $out/${tag}_hbm_traffic_k100.json profiles/hbm_traffic_k100.json
+fi
+if [ "$phase" = "mfma" ] || [ "$phase" = "all" ]; then
+# matrix-pipe utilisation: one SQ + GRBM pass per atom count (counters only, with --kernel-trace for the durations)
+cd /tmp
+rocprofv3 -L > $out/${tag}_counters_avail.txt 2>&1
+ctrs="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
+for K in 50 100; do
+  K=$K rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/pmc_${tag}_k${K}_mfma -- python3 $root/tools/bench_kernels.py > $out/pmc_${tag}_k${K}_mfma.log 2>&1 || exit 1
+done
+cd $root
+K=50 python3 tools/pmc_mfma.py $out/pmc_${tag}_k50_mfma > $out/${tag}_mfma_utilisation_k50.md || exit 1
+K=100 python3 tools/pmc_mfma.py $out/pmc_${tag}_k100_mfma > $out/${tag}_mfma_utilisation_k100.md || exit 1
+find $out -path "*pmc_${tag}_k*_mfma*" -name "*kernel_trace.csv" -delete
 fi
 if [ "$phase" = "lines" ] || [ "$phase" = "all" ]; then
 cd $root
