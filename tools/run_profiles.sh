@@ -5,7 +5,7 @@
 # the kernel sources is written next to them and into hbm_traffic*.json (bench.py reports roofline.traffic only for it).
 set -o pipefail
 tag=${1:-r03}
-phase=${2:-all}          # stats | pmc | mfma | lines | all   (one gpurun call holds 20 minutes: stats and pmc+lines fit one each)
+phase=${2:-all}          # stats | pmc | mfma | sq | lines | all   (one gpurun call holds 20 minutes: stats and pmc+lines fit one each)
 root=$(pwd)
 export TMPDIR=/tmp
 out=$root/gpurun_out
@@ -55,6 +55,18 @@ cd $root
 K=50 python3 tools/pmc_mfma.py $out/pmc_${tag}_k50_mfma > $out/${tag}_mfma_utilisation_k50.md || exit 1
 K=100 python3 tools/pmc_mfma.py $out/pmc_${tag}_k100_mfma > $out/${tag}_mfma_utilisation_k100.md || exit 1
 find $out -path "*pmc_${tag}_k*_mfma*" -name "*kernel_trace.csv" -delete
+fi
+if [ "$phase" = "sq" ] || [ "$phase" = "all" ]; then
+# LDS bank conflicts + where the wave cycles go: one pass of 8 SQ counters per atom count
+cd /tmp
+sq="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
+for K in 50 100; do
+  K=$K rocprofv3 --pmc $sq --kernel-trace --output-format csv -d $out/pmc_${tag}_k${K}_sq -- python3 $root/tools/bench_kernels.py > $out/pmc_${tag}_k${K}_sq.log 2>&1 || exit 1
+done
+cd $root
+K=50 python3 tools/pmc_sq.py $out/pmc_${tag}_k50_sq > $out/${tag}_lds_conflicts_and_stalls_k50.md || exit 1
+K=100 python3 tools/pmc_sq.py $out/pmc_${tag}_k100_sq > $out/${tag}_lds_conflicts_and_stalls_k100.md || exit 1
+find $out -path "*pmc_${tag}_k*_sq*" -name "*kernel_trace.csv" -delete
 fi
 if [ "$phase" = "lines" ] || [ "$phase" = "all" ]; then
 cd $root
