@@ -15,15 +15,9 @@ DEFAULT_IMAGE = 'data/ImageNet/ILSVRC/Data/val/n01484850/ILSVRC2012_val_00002752
 def load_image(path, size=224):
     """Resize(256) / CenterCrop(224) / ToTensor of the reference (main.py:64-75) without torchvision."""
     from PIL import Image
-    import numpy as np
-    im = Image.open(path).convert("RGB")
-    w, h = im.size
-    scale = 256 / min(w, h)
-    im = im.resize((max(256, round(w * scale)), max(256, round(h * scale))), Image.BILINEAR)
-    w, h = im.size
-    left, top = (w - size) // 2, (h - size) // 2
-    im = im.crop((left, top, left + size, top + size))
-    return torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).permute(2, 0, 1).contiguous()
+    from DS_ImageNet import transform
+    with open(path, 'rb') as f:
+        return transform(Image.open(f), crop=size)
 
 
 def build_parser():
