@@ -297,8 +297,9 @@ def test_main_load_image_follows_the_reference_transform(tmp_path):
     PIL.fromarray(arr).save(path)
     x = main_cli.load_image(str(path))
     assert x.shape == (3, 224, 224) and x.dtype == torch.float32 and 0.0 <= float(x.min()) and float(x.max()) <= 1.0
-    im = PIL.open(path).convert("RGB").resize((round(480 * 256 / 300), 256), PIL.BILINEAR)   # (410, 256)
-    left, top = (im.size[0] - 224) // 2, (256 - 224) // 2
+    # torchvision's arithmetic: the longer side is TRUNCATED (int(409.6) = 409), the crop offset rounds half to even (92.5 -> 92)
+    im = PIL.open(path).convert("RGB").resize((int(480 * 256 / 300), 256), PIL.BILINEAR)     # (409, 256)
+    left, top = int(round((im.size[0] - 224) / 2.0)), (256 - 224) // 2
     want = torch.from_numpy(np.asarray(im.crop((left, top, left + 224, top + 224)), dtype=np.float32) / 255).permute(2, 0, 1)
     assert torch.equal(x, want)
     # a portrait image: the WIDTH becomes 256
