@@ -52,6 +52,9 @@ def build_parser():
                    help='validate every this many epochs (0 = after the last epoch only); the dictionary file is the same')
     p.add_argument('--upload-workers', type=int, default=0,
                    help='worker processes fetching the dataset items for the one-time upload into HBM (JPEG decoding)')
+    p.add_argument('--clean-accuracy', type=int, default=1,
+                   help='1 (default, as upstream): print the clean top-1 accuracy of the classifier over the whole dataset '
+                        'first (model_accuracy.py); 0 skips that pass')
     p.add_argument('--fast-classifier', type=int, default=1,
                    help='bf16 ResNets: run the frozen classifier on the hand-written stem / pointwise / 3x3 kernels '
                         '(zoo.FusedResNet, same function up to bf16 rounding); 0 = plain PyTorch modules')
@@ -113,6 +116,12 @@ def main(args):
         weights = _fitted_weights(model_name, args.seed, train_dataset, n_classes, device)
     model = zoo.build_classifier(model_name, seed=args.seed, weights=weights, device=device, dtype=dtype,
                                  channels_last=fast, fuse_bn_act=fast, fuse_stem=fast)
+    if args.clean_accuracy:                                                               # demo_dL_attack.py:65-66
+        from model_accuracy import model_accuracy, model_accuracy_distributed
+        dataset.indexed = False
+        acc = (model_accuracy_distributed(dataset, model, device) if torch.distributed.is_initialized()
+               else model_accuracy(dataset, model, device=device))
+        print("accuracy of the the model {} is {}".format(model_name, float(acc) * 100))
     val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=10, shuffle=False)
     test_loader = torch.utils.data.DataLoader(test_dataset, batch_size=20, shuffle=False)
 

@@ -92,3 +92,61 @@ def test_main_py_load_image_is_the_same_transform(tmp_path):
     p = os.path.join(str(tmp_path), "a.png")
     Image.fromarray(np.random.RandomState(1).randint(0, 256, (257, 300, 3), dtype=np.uint8)).save(p)
     assert torch.equal(M.load_image(p), D.transform(Image.open(p)))
+
+
+class _Labelled(torch.utils.data.Dataset):
+    def __init__(self, x, y):
+        self.x, self.y = x, y
+
+    def __len__(self):
+        return len(self.y)
+
+    def __getitem__(self, i):
+        return self.x[i], int(self.y[i])
+
+
+def _accuracy_problem(n=300):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, 3, 4, 4, generator=g)
+    net = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(48, 5))
+    with torch.no_grad():
+        truth = net(x).argmax(-1)
+    y = truth.clone()
+    y[::4] = (y[::4] + 1) % 5                                  # every fourth label is wrong: accuracy = 225 / 300
+    return _Labelled(x, y), net
+
+
+def test_model_accuracy_is_correct_over_seen():
+    from model_accuracy import model_accuracy
+    data, net = _accuracy_problem()
+    acc = model_accuracy(data, net, device="cpu")
+    assert acc.dim() == 0 and acc.dtype == torch.float32 and abs(float(acc) - 0.75) < 1e-7
+    assert abs(float(model_accuracy(data, net.to(torch.bfloat16), device="cpu", batch_size=7)) - 0.75) < 0.03   # inputs follow the model's dtype
+    assert float(model_accuracy(_Labelled(data.x[:0], data.y[:0]), net, device="cpu")) == 0.0
+
+
+def _accuracy_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from dl_attack_on_imagenet_amd import dist as adist
+    from model_accuracy import model_accuracy_distributed
+    adist.init_from_env(backend="gloo")
+    data, net = _accuracy_problem(301)                          # 301 images: the shards are uneven, nothing is counted twice
+    torch.save(model_accuracy_distributed(data, net, "cpu", batch_size=16), os.path.join(out, f"acc{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_model_accuracy_distributed_counts_every_image_once(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    from model_accuracy import model_accuracy
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.start_processes(_accuracy_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    data, net = _accuracy_problem(301)
+    want = float(model_accuracy(data, net))
+    got = [float(torch.load(os.path.join(str(tmp_path), f"acc{r}.pt"))) for r in range(2)]
+    assert got[0] == got[1] and abs(got[0] - want) < 1e-7

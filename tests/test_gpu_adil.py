@@ -436,7 +436,7 @@ def test_uappgd_baseline_matches_reference_run(tag, norm, optim, tmp_path):
     close(adv, (images + t(z[f"{tag}_attack"])).clamp(0, 1), 2e-5)
 
 
-def test_demo_cli_result_dumps(tmp_path, monkeypatch):
+def test_demo_cli_result_dumps(tmp_path, monkeypatch, capsys):
     """demo_dL_attack.py end to end on a seeded synthetic dataset: the dictionary file is named after the CLI's model
     string as upstream (trained_dicts/ImageNet_resnet.bin, adil.py:89-91) and the two result dumps carry the reference's
     file names and layout (demo_dL_attack.py:148-156: {'fooling_rate','rmse','mse','time'} -> {sub_name: [values]})."""
@@ -447,6 +447,10 @@ def test_demo_cli_result_dumps(tmp_path, monkeypatch):
          "--n-atoms", "4", "--steps", "2", "--batch-size", "2", "--steps-inference", "3"])
     torch.random.manual_seed(args.seed)
     val_perf, test_perf = demo_dL_attack.main(args)
+    # the clean-accuracy pass the reference runs first (demo_dL_attack.py:65-66, model_accuracy.py): over all 150 structured
+    # images, of which the head was fitted to the 3 of the training split (one per class)
+    said = [l for l in capsys.readouterr().out.splitlines() if l.startswith("accuracy of the the model resnet is ")]
+    assert len(said) == 1 and float(said[0].rsplit(" ", 1)[1]) >= 90.0
     d, v, loss_all, fooling_rate_all, val_fool = torch.load("trained_dicts/ImageNet_resnet.bin", map_location="cpu")
     assert d.shape == (3, 64, 64, 4) and v.shape == (3, 4) and len(loss_all) == 2 and len(fooling_rate_all) == 2
     out = "dict_model_ImageNet_version_constrained"
