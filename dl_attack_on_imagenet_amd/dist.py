@@ -37,6 +37,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     driver only supports dmabuf IPC, and with the legacy IPC mode RCCL's (and torch's) cross-process sharing of device
     memory fails with `hipIpcGetMemHandle: invalid argument`.  The ROCr runtime reads the variable when it is
     initialised, so it has to be in place before `torch.cuda.*` touches the device — callers invoke init_from_env first."""
+    adopt_slurm_env()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -51,6 +52,38 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
             torch.cuda.set_device(local_device_index(local_rank))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def first_host(nodelist: str) -> str:
+    """First host of a SLURM node list: 'gpu[017-020,031],login1' -> 'gpu017' (what hostlist.expand_hostlist(...)[0] gives
+    the reference, env_setting.py:10-11; the `hostlist` package is not in this image)."""
+    head = nodelist.strip()
+    lb = head.find("[")
+    comma = head.find(",")
+    if lb < 0 or (0 <= comma < lb):
+        return head.split(",", 1)[0]
+    rb = head.index("]", lb)
+    first = head[lb + 1:rb].split(",", 1)[0].split("-", 1)[0]
+    tail = head[rb + 1:].split(",", 1)[0]
+    return head[:lb] + first + tail
+
+
+def adopt_slurm_env() -> bool:
+    """Under `srun` without torchrun (how the reference launches, env_setting.py:7-16): translate SLURM's task variables into
+    the RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT this package reads — rank SLURM_PROCID of SLURM_NTASKS,
+    device SLURM_LOCALID, rendezvous at the first host of the job's node list, port 12345 + the lowest GPU id of the step
+    (env_setting.py:25).  Nothing is touched when torchrun's variables are present."""
+    env = os.environ
+    if "WORLD_SIZE" in env or "RANK" in env or "SLURM_NTASKS" not in env or "SLURM_PROCID" not in env:
+        return False
+    env["WORLD_SIZE"], env["RANK"] = env["SLURM_NTASKS"], env["SLURM_PROCID"]
+    env["LOCAL_RANK"] = env.get("SLURM_LOCALID", "0")
+    nodes = env.get("SLURM_JOB_NODELIST") or env.get("SLURM_STEP_NODELIST")
+    if nodes:
+        env.setdefault("MASTER_ADDR", first_host(nodes))
+    gpus = [int(g) for g in env.get("SLURM_STEP_GPUS", "").split(",") if g.strip().isdigit()]
+    env.setdefault("MASTER_PORT", str(12345 + (min(gpus) if gpus else 0)))
+    return True
 
 
 def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:

@@ -223,3 +223,23 @@ def test_init_from_env_single_process(monkeypatch):
     assert adist.init_from_env() == (0, 1, 0)
     with pytest.raises(RuntimeError):
         adist.DictGradReducer()
+
+
+def test_slurm_environment_is_adopted(monkeypatch):
+    """srun without torchrun (the reference's launch, env_setting.py:7-16, 25): SLURM's task variables become the
+    rendezvous this package reads; torchrun's own variables win when present."""
+    sys.path.insert(0, ROOT)
+    from dl_attack_on_imagenet_amd import dist as adist
+    assert adist.first_host("gpu[017-020,031],login1") == "gpu017"
+    assert adist.first_host("node7") == "node7" and adist.first_host("a1,b[2-3]") == "a1"
+    assert adist.first_host("rack[3,5-6]-ib") == "rack3-ib"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.setenv(k, "placeholder")                      # registered with monkeypatch, so whatever the code under
+        monkeypatch.delenv(k)                                      # test writes is rolled back to the original state
+    for k, v in dict(SLURM_NTASKS="1", SLURM_PROCID="0", SLURM_LOCALID="0", SLURM_JOB_NODELIST="gpu[017-020]",
+                     SLURM_STEP_GPUS="5,4").items():
+        monkeypatch.setenv(k, v)
+    assert adist.init_from_env() == (0, 1, 0)                      # one task: no process group, but the env is translated
+    assert os.environ["MASTER_ADDR"] == "gpu017" and os.environ["MASTER_PORT"] == str(12345 + 4)
+    monkeypatch.setenv("SLURM_PROCID", "3")
+    assert adist.adopt_slurm_env() is False and os.environ["RANK"] == "0"      # already translated / torchrun present: untouched
