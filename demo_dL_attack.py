@@ -78,7 +78,8 @@ def spawn_ranks(args):
 
 
 def main(args):
-    if args.distributed and "WORLD_SIZE" not in os.environ and torch.cuda.device_count() > 1:
+    under_srun = int(os.environ.get("SLURM_NTASKS", "1")) > 1 and "SLURM_PROCID" in os.environ      # the reference's launch form
+    if args.distributed and "WORLD_SIZE" not in os.environ and not under_srun and torch.cuda.device_count() > 1:
         raise SystemExit(spawn_ranks(args))
     if args.distributed:
         from dl_attack_on_imagenet_amd import dist as adist
@@ -92,7 +93,7 @@ def main(args):
     else:
         # one process per GPU (torchrun env); the process group also shards the evaluation below over the ranks
         from dl_attack_on_imagenet_amd import dist as adist
-        _, _, local_rank = adist.init_from_env()
+        _, _, local_rank = adist.init_from_env(slurm=True)        # torchrun's variables, else srun's (env_setting.py:7-16)
         device = torch.device('cuda', adist.local_device_index(local_rank))
         torch.cuda.set_device(device)
 

@@ -26,7 +26,7 @@ def local_device_index(local_rank: int) -> int:
 IPC_ENV = "HSA_ENABLE_IPC_MODE_LEGACY"
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+def init_from_env(backend: Optional[str] = None, slurm: bool = False) -> Tuple[int, int, int]:
     """(rank, world_size, local_rank) from torchrun's env; initialises the default process group when
     WORLD_SIZE > 1.  backend: argument, else $ADIL_DIST_BACKEND, else 'nccl' (= RCCL on ROCm) when a GPU is
     present, else 'gloo'.
@@ -36,8 +36,13 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     first HIP call, unless the caller exported a value.  Source: the deployment notes of this MI355X pool — the host
     driver only supports dmabuf IPC, and with the legacy IPC mode RCCL's (and torch's) cross-process sharing of device
     memory fails with `hipIpcGetMemHandle: invalid argument`.  The ROCr runtime reads the variable when it is
-    initialised, so it has to be in place before `torch.cuda.*` touches the device — callers invoke init_from_env first."""
-    adopt_slurm_env()
+    initialised, so it has to be in place before `torch.cuda.*` touches the device — callers invoke init_from_env first.
+
+    slurm=True: under plain `srun` (no torchrun variables) take rank / world size / rendezvous from SLURM's task variables
+    first (`adopt_slurm_env`) — the reference's launch form; never implied, so that a single-process run that merely sits inside
+    a multi-task allocation is not turned into rank 0 of N."""
+    if slurm:                            # opt-in (the demo's --distributed): a bench run inside a SLURM allocation stays one process
+        adopt_slurm_env()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

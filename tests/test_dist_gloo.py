@@ -239,7 +239,10 @@ def test_slurm_environment_is_adopted(monkeypatch):
     for k, v in dict(SLURM_NTASKS="1", SLURM_PROCID="0", SLURM_LOCALID="0", SLURM_JOB_NODELIST="gpu[017-020]",
                      SLURM_STEP_GPUS="5,4").items():
         monkeypatch.setenv(k, v)
-    assert adist.init_from_env() == (0, 1, 0)                      # one task: no process group, but the env is translated
+    monkeypatch.setenv("SLURM_NTASKS", "8")
+    assert adist.init_from_env() == (0, 1, 0) and "WORLD_SIZE" not in os.environ   # never implied: a bench run inside an allocation
+    monkeypatch.setenv("SLURM_NTASKS", "1")
+    assert adist.init_from_env(slurm=True) == (0, 1, 0)            # one task: no process group, but the env is translated
     assert os.environ["MASTER_ADDR"] == "gpu017" and os.environ["MASTER_PORT"] == str(12345 + 4)
     monkeypatch.setenv("SLURM_PROCID", "3")
     assert adist.adopt_slurm_env() is False and os.environ["RANK"] == "0"      # already translated / torchrun present: untouched
