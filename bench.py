@@ -396,6 +396,7 @@ def bench_transfer(args, rank, world, dev, timer):
                    "rmse": next(iter(result.values()))["rmse"]},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, K),
+                     "mfma_utilisation": measured_mfma_utilisation(dom, K),
                      "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern_ms[dom], "launches_timed": launches[dom],
                      "empty_event_bracket_ms": timer.empty_bracket_ms()},
         "kernels_ms_per_launch": kern_ms, "kernel_launches_timed": launches,
@@ -416,6 +417,22 @@ def measured_traffic(group, atoms):
     try:
         from dl_attack_on_imagenet_amd.build import source_hash
         rec = json.load(open(tpath))
+        if rec.get("_source", {}).get("kernel_source_hash") != source_hash() or rec.get("_source", {}).get("atoms", 50) != atoms:
+            return None
+        return rec.get(group)
+    except Exception:
+        return None
+
+
+def measured_mfma_utilisation(group, atoms):
+    """Share of the matrix pipes' cycles the group's kernel keeps busy, from the PMC pass of tools/run_profiles.sh mfma
+    (profiles/mfma_utilisation*.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)); like the traffic, only
+    when the file was collected from THIS build of the kernels at this atom count, otherwise null.  Supporting evidence:
+    the bound of every kernel on the path is HBM."""
+    mpath = os.path.join(ROOT, "profiles", "mfma_utilisation.json" if atoms == 50 else f"mfma_utilisation_k{atoms}.json")
+    try:
+        from dl_attack_on_imagenet_amd.build import source_hash
+        rec = json.load(open(mpath))
         if rec.get("_source", {}).get("kernel_source_hash") != source_hash() or rec.get("_source", {}).get("atoms", 50) != atoms:
             return None
         return rec.get(group)
@@ -588,6 +605,7 @@ def main():
                    ("train_fooling_rate_last_step" if args.mode == "learn" else "fooling_rate_after_timed_iterations"): fool_rate},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "mfma_utilisation": measured_mfma_utilisation(dom, K),     # PMC pass of this build, else null
                      "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern_ms[dom],
                      "empty_event_bracket_ms": timer.empty_bracket_ms(),
                      # informational: the same with the cost of an empty event bracket taken off (this is the figure that

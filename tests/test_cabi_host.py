@@ -368,6 +368,20 @@ def test_bench_defaults_by_mode_and_traffic_is_tied_to_the_build(tmp_path, monke
     rec["_source"]["kernel_source_hash"] = "0" * 16                                      # measured on another build
     json.dump(rec, open(tmp_path / "profiles" / "hbm_traffic.json", "w"))
     assert bench.measured_traffic("synth", 50) is None
+    assert bench.measured_mfma_utilisation("synth", 50) is None                          # same rule for the MFMA pass: no file
+    mrec = {"_source": {"kernel_source_hash": source_hash(), "atoms": 50}, "synth": 0.05}
+    json.dump(mrec, open(tmp_path / "profiles" / "mfma_utilisation.json", "w"))
+    assert bench.measured_mfma_utilisation("synth", 50) == 0.05 and bench.measured_mfma_utilisation("synth", 100) is None
+    mrec["_source"]["kernel_source_hash"] = "0" * 16
+    json.dump(mrec, open(tmp_path / "profiles" / "mfma_utilisation.json", "w"))
+    assert bench.measured_mfma_utilisation("synth", 50) is None
+    # the committed files should belong to the committed kernel tree (else the bench line carries nulls for them); a warning,
+    # not a failure: while a kernel is being changed the counters are stale until `tools/run_profiles.sh` has run again
+    import warnings
+    for name in ("hbm_traffic.json", "hbm_traffic_k100.json", "mfma_utilisation.json", "mfma_utilisation_k100.json"):
+        committed = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if committed["_source"]["kernel_source_hash"] != source_hash():
+            warnings.warn(f"profiles/{name} was measured on another kernel tree: re-run tools/run_profiles.sh pmc / mfma")
     a50 = bench.algorithmic_bytes(512, 150528, 50, 512, 2, "learn")
     assert a50["synth"] == 2 * 512 * 150528 * 2 + 150528 * 50 * 4 + 512 * 50 * 4          # 338.5 MB
 

@@ -2,7 +2,10 @@
 
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE [SQ_INSTS_MFMA ...] --kernel-trace --output-format csv \
         -d gpurun_out/pmc_mfma -- python3 tools/bench_kernels.py
-    python tools/pmc_mfma.py gpurun_out/pmc_mfma > profiles/rNN_mfma_utilisation.md
+    python tools/pmc_mfma.py gpurun_out/pmc_mfma [profiles/mfma_utilisation.json] > profiles/rNN_mfma_utilisation.md
+
+The optional JSON (per launch group of bench.py, with the hash of the kernel sources it was measured on) is what
+`bench.py` reports as `roofline.mfma_utilisation` — like `roofline.traffic`, only for the build it was collected from.
 
 Units as MI355X_MICROARCH.md states them: SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles, summed over every SIMD of the
 chip (= 32 x the number of v_mfma_f32_32x32x16_bf16 wave-instructions); GRBM_GUI_ACTIVE is the sum over the 8 XCDs, so
@@ -11,6 +14,7 @@ utilisation = busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): the fraction of 
 at the clock the kernel actually ran at; `of dense peak` prices the same MFMAs against 2.5 PFLOP/s at 2.4 GHz."""
 import csv
 import glob
+import json
 import os
 import re
 import sys
@@ -51,6 +55,7 @@ def main():
     print("| kernel | launches | avg µs (this pass) | MFMA busy cycles / launch | = 32x32x16 MFMAs / launch | effective clock | "
           "matrix-pipe utilisation | MFMA TFLOP/s (of 2 500 dense bf16) |")
     print("|---|---|---|---|---|---|---|---|")
+    utils = {}
     for k in sorted(per):
         disp = [x for x in per[k] if x in dur and "SQ_VALU_MFMA_BUSY_CYCLES" in per[k][x]]
         disp = disp[len(disp) // 4:] if len(disp) >= 8 else disp          # drop warm-up launches
@@ -64,8 +69,22 @@ def main():
         util = busy / (SIMDS * gui / 8) if gui else float("nan")
         mfmas = busy / 32
         tflops = mfmas * 32 * 32 * 16 * 2 / t / 1e12
+        utils[k] = util
         print(f"| `{k}` | {n} | {t * 1e6:.1f} | {busy / 1e6:.2f} M | {mfmas / 1e6:.3f} M | {clock / 1e9:.2f} GHz | "
               f"{util * 100:.1f} % | {tflops:.0f} ({tflops / PEAK_TFLOPS * 100:.0f} %) |")
+    if len(sys.argv) > 2:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from dl_attack_on_imagenet_amd.build import source_hash
+        groups = {"synth": "synth_mfma_kernel<bf16", "grad": "grad_fused_mfma_kernel<bf16", "zstep_": "zstep_mfma_kernel",
+                  "grad[z D_dagger^T]": "grad_v_f32_kernel"}
+        rec = {"_source": {"counters": path, "kernel_source_hash": source_hash(), "atoms": int(os.environ.get("K", 50)),
+                           "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)"},
+               "_kernels": utils}
+        for g, prefix in groups.items():
+            sel = [u for k, u in sorted(utils.items()) if k.startswith(prefix) and u == u]
+            if sel:
+                rec[g] = sel[0]
+        json.dump(rec, open(sys.argv[2], "w"), indent=1)
 
 
 if __name__ == "__main__":

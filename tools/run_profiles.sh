@@ -52,8 +52,10 @@ for K in 50 100; do
   K=$K rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/pmc_${tag}_k${K}_mfma -- python3 $root/tools/bench_kernels.py > $out/pmc_${tag}_k${K}_mfma.log 2>&1 || exit 1
 done
 cd $root
-K=50 python3 tools/pmc_mfma.py $out/pmc_${tag}_k50_mfma > $out/${tag}_mfma_utilisation_k50.md || exit 1
-K=100 python3 tools/pmc_mfma.py $out/pmc_${tag}_k100_mfma > $out/${tag}_mfma_utilisation_k100.md || exit 1
+K=50 python3 tools/pmc_mfma.py $out/pmc_${tag}_k50_mfma $out/${tag}_mfma_utilisation.json > $out/${tag}_mfma_utilisation_k50.md || exit 1
+K=100 python3 tools/pmc_mfma.py $out/pmc_${tag}_k100_mfma $out/${tag}_mfma_utilisation_k100.json > $out/${tag}_mfma_utilisation_k100.md || exit 1
+cp $out/${tag}_mfma_utilisation.json profiles/mfma_utilisation.json
+cp $out/${tag}_mfma_utilisation_k100.json profiles/mfma_utilisation_k100.json
 find $out -path "*pmc_${tag}_k*_mfma*" -name "*kernel_trace.csv" -delete
 fi
 if [ "$phase" = "sq" ] || [ "$phase" = "all" ]; then
