@@ -7,6 +7,9 @@ out=gpurun_out
 for m in learn inference learn_k100 inference_k100 transfer; do cp $out/${tag}_${m}_bench_stats.md profiles/${tag}_${m}_bench_stats.md; done
 cp $out/${tag}_hbm_traffic.json profiles/hbm_traffic.json
 cp $out/${tag}_hbm_traffic_k100.json profiles/hbm_traffic_k100.json
+for f in mfma_utilisation mfma_utilisation_k100; do     # the `mfma` phase (matrix-pipe utilisation; roofline.mfma_utilisation of the bench line)
+  if [ -f $out/${tag}_$f.json ]; then cp $out/${tag}_$f.json profiles/$f.json; fi
+done
 for f in ${tag}_bench_line ${tag}_bench_line_inference ${tag}_bench_line_transfer; do grep "^{" $out/$f.json | tail -1 > profiles/$f.json; done
 {
   echo "# One steady-state learning step of \`bench.py\` (rocprofv3 kernel trace, run ${tag}) — where the time goes"; echo
