@@ -916,7 +916,11 @@ def test_bench_transfer_mode_line(tmp_path):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["unit"] == "images/sec" and line["value"] > 0
     assert set(line["config"]["transfer_fooling_rates"]) == {"resnet18", "densenet121", "googlenet", "inception_v3", "mobilenet_v2", "vgg11"}
-    assert line["roofline"]["kernel"] == "zstep_" and line["roofline"]["launches_timed"] == 2 * 5
+    # the roofline kernel = the launch group with the largest total time: the z-step at any real size; at this plumbing size
+    # (4 images, 10 atoms) every kernel is launch latency and the two contractions of an iteration (`grad`: z D_dagger^T and
+    # g D, two launches each iteration) can add up to more than the one z-step launch
+    kern = line["roofline"]["kernel"]
+    assert kern in ("zstep_", "grad") and line["roofline"]["launches_timed"] == 2 * 5 * (1 if kern == "zstep_" else 2)
     assert line["config"]["ddrague_iterations_run_per_batch"] == 5
     # two ranks (one-GPU rehearsal: gloo, shared card): performance.py deals batch i to rank i % 2, each rank keeps only its
     # own batches resident, the final sums are all-reduced; the line says which backend it ran on
@@ -952,7 +956,9 @@ def test_bench_inference_and_learn_mode_lines(tmp_path):
         return json.loads(lines[0])
 
     inf = line("--mode", "inference")
-    assert inf["roofline"]["kernel"] == "zstep_" and inf["unit"] == "images/sec" and inf["n_gpus"] == 1 and inf["steps"] == 3
+    # the z-step at any real size; at 8 images x 10 atoms every launch is latency and any of the iteration's kernels can be slowest
+    assert inf["roofline"]["kernel"] in ("zstep_", "grad", "grad[z D_dagger^T]", "synth")
+    assert inf["unit"] == "images/sec" and inf["n_gpus"] == 1 and inf["steps"] == 3
     assert set(inf["kernels_ms_per_step"]) >= {"grad[z D_dagger^T]", "synth", "grad", "zstep_", "pack_codes"}
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in inf["roofline"]
