@@ -65,8 +65,8 @@ def parse_args():
     p.add_argument("--fp8-synth", type=int, default=0,
                    help="1: the D.V contraction of the synthesis on fp8 (e4m3) MFMAs (BASELINE.json configs[4]); learn mode")
     p.add_argument("--cpu-baseline", type=int, default=1)
-    p.add_argument("--cpu-batch", type=int, default=64, help="images of the config-2-shape CPU sample (64 images x 1 step: ~15-20 s "
-                                                             "on the box's host cores)")
+    p.add_argument("--cpu-batch", type=int, default=48, help="images of the config-2-shape CPU sample (48 images x 1 step per "
+                                                             "pseudo-label policy: ~12 + ~18 s on the box's host cores)")
     p.add_argument("--cpu-steps", type=int, default=1)
     p.add_argument("--cpu-config1", type=int, default=1, help="also run configs[0] (resnet18, 32 images, 10 atoms, 20 "
                                                               "iterations, fp32) in full on the host cores and on the GPU")
@@ -81,7 +81,7 @@ def parse_args():
 class KernelTimer:
     """Brackets every launch group of the hand-written kernels with HIP events on the launch stream."""
 
-    GROUPS = ("pack_codes", "synth", "grad", "adamw_clamp_", "adamw_l1ball_", "zstep_")
+    GROUPS = ("pack_codes", "synth", "grad", "adamw_clamp_", "adamw_l1ball_", "zstep_", "zstep_codes_")
 
     def __init__(self, ops):
         self.ops, self.enabled, self.records, self.empty = ops, False, {}, []
@@ -131,6 +131,10 @@ def algorithmic_bytes(B, P, K, N, s, mode="learn"):
             "synth": 2 * B * P * s + P * K * 4 + B * K * 4,            # read x, write x + D v, read D
             "grad": B * P * s + P * K * 4 + B * K * 4,                 # read g, read D, write dL/dv
             "zstep_": 6 * B * P * 4 + P * K * 4 + B * K * 4,           # z, m, s read + written; D_dagger; dL/dv
+            # round 4: the z-step that also produces the next iteration's codes (adil_zstep_codes): the same streams — the
+            # contraction's own pass over z and D_dagger ("grad[z D_dagger^T]" above) is what the fusion removes, so it is
+            # NOT credited here — plus the codes it writes
+            "zstep_codes_": 6 * B * P * 4 + P * K * 4 + 2 * B * K * 4,
             "pack_codes": 2 * B * K * 4,
         }
     return {
@@ -238,12 +242,26 @@ def cpu_baseline(args, P_shape, dev):
         od, ov = O.AdamWState(d, 0.01), O.AdamWState(v, 0.01)
         index = torch.arange(b)
         O.learn_step_a(model, x[:2], index[:2], d, v, od, ov, 8 / 255, args.loss, -1.0, 50.0)   # warm-up
-        t0 = time.perf_counter()
-        for _ in range(args.cpu_steps):
-            O.learn_step_a(model, x, index, d, v, od, ov, 8 / 255, args.loss, -1.0, 50.0)
-        dt = time.perf_counter() - t0
-        what = f"{args.cpu_steps} learning step(s) of the CPU oracle (oracle/adil_oracle.py learn_step_a)"
+        # the CPU figure beside `value` follows the SAME pseudo-label policy as `value` (cached labels by
+        # default: 1 forward + 1 backward per step; the labels are handed in, as engine.LabelCache does from an image's
+        # second visit on), and the other policy — the reference's own sequence, recomputing them: 2 forwards + 1
+        # backward — is timed right after it on the same sample
+        with torch.no_grad():
+            cached = model(x).argmax(dim=-1)
+        timings = {}
+        for policy in (("cached", "recomputed") if args.cache_labels else ("recomputed", "cached")):
+            t0 = time.perf_counter()
+            for _ in range(args.cpu_steps):
+                O.learn_step_a(model, x, index, d, v, od, ov, 8 / 255, args.loss, -1.0, 50.0,
+                               labels=cached if policy == "cached" else None)
+            timings[policy] = time.perf_counter() - t0
+        same, other = ("cached", "recomputed") if args.cache_labels else ("recomputed", "cached")
+        dt = timings[same]
+        what = (f"{args.cpu_steps} learning step(s) of the CPU oracle (oracle/adil_oracle.py learn_step_a) with the pseudo-labels "
+                f"{'handed in (cached policy, 1 fwd + 1 bwd: the policy of `value`)' if args.cache_labels else 'recomputed (2 fwd + 1 bwd: the policy of `value`)'}"
+                f"; the other policy ({other}) took {timings[other]:.1f} s on the same sample")
         value = b * args.cpu_steps / dt
+        other_value = b * args.cpu_steps / timings[other]
         # "separately, seconds per step of the dictionary ops alone" — the reference's op sequence without
         # the classifier (synthesis, backward through the tensordot for a given dLoss/dx, AdamW on D and all code rows,
         # l1 projection, clamp) at the FULL batch of the workload; compare with `dictionary_path_ms_per_step` of the GPU
@@ -263,6 +281,8 @@ def cpu_baseline(args, P_shape, dev):
                      f"cores; configs[1] shape ({args.model}, {k} atoms, {P_shape[1]}x{P_shape[2]}) on {b} of its "
                      f"{args.batch} images per step; {dt:.1f} s"}
     if args.mode == "learn":
+        out["label_policy"] = same
+        out["value_recomputed_labels" if args.cache_labels else "value_cached_labels"] = other_value
         out["dictionary_ops_alone_ms_per_step"] = dict_only_ms
         out["dictionary_ops_alone_note"] = (f"synthesis + backward through the tensordot + AdamW(D, all rows of V) + l1 projection + clamp "
                                             f"on the host cores at the full batch of {args.batch} images, no classifier (one step)")
@@ -375,7 +395,7 @@ def bench_transfer(args, rank, world, dev, timer):
     alg = algorithmic_bytes(B, P, K, B, s_bytes, "inference")
     dom = max((k for k in kern_ms if k in alg), key=lambda k: kern_ms[k] * launches[k])
     achieved = alg[dom] / (kern_ms[dom] * 1e-3) / 1e9
-    iters_run = launches.get("zstep_", 0) / max(args.steps, 1)
+    iters_run = (launches.get("zstep_", 0) + launches.get("zstep_codes_", 0)) / max(args.steps, 1)
     out = {
         "metric": "attacked images/sec (transfer evaluation: full attack(x, y) + six targets scored, classifiers included)",
         "value": world * B * args.steps / elapsed, "unit": "images/sec",
@@ -623,6 +643,16 @@ def main():
         out["value_reference_op_sequence_recomputed_labels"] = (other_variant if args.cache_labels else
                                                                 {"images_per_sec": out["value"], "ms_per_step": out["ms_per_step"]})["images_per_sec"]
         out["value_cached_labels"] = out["value"] if args.cache_labels else other_variant["images_per_sec"]
+        # `value` changed definition between BENCH_r02 (recomputed labels, 2 fwd + 1 bwd) and BENCH_r03 onwards
+        # (cached labels, 1 fwd + 1 bwd).  Round-over-round tracking compares `value_reference_op_sequence_recomputed_labels`
+        # with r02's `value`; `cpu_baseline.value` follows the policy of `value` and carries the other policy next to it.
+        out["value_definition"] = (
+            ("clean pseudo-labels cached per image (1 classifier forward + 1 backward per step; the learners' default since "
+             "round 3, result-neutral: SURVEY.md section 8(d), quirk Q4, profiles/r03_label_stability.md)" if args.cache_labels else
+             "clean pseudo-labels recomputed in every step (the reference's op sequence, 2 forwards + 1 backward)")
+            + "; BENCH_r02.value used the recomputing sequence: compare it with value_reference_op_sequence_recomputed_labels. "
+              "The bench replays one resident batch, so the cache always hits — as it does from an image's second epoch on in a "
+              "run of the learner (500 epochs in demo_dL_attack.py:92); the first epoch pays the reference's sequence.")
     if rank == 0 and world == 1 and args.cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, shape, dev)
     if rank == 0:

@@ -30,6 +30,10 @@ SIGNATURES = {
     "adil_zstep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
                            c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_float, c_void_p,
                            c_void_p, c_void_p]),
+    "adil_zstep_codes_slab_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "adil_zstep_codes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
+                                 c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_float, c_void_p,
+                                 c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "adil_adamw_l1ball": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
                                   c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                   c_void_p, c_int, c_int, c_void_p]),
@@ -61,7 +65,7 @@ SIGNATURES = {
                                    c_void_p]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

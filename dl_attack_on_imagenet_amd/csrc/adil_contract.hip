@@ -1531,6 +1531,201 @@ __global__ __launch_bounds__(NW * 64) void grad_v_f32_kernel(const float* __rest
 }
 
 // =========================================================================================================== //
+// K8 + K6 in one pass: the z-step above AND the codes of the NEXT DDrague iteration, v' = z_new D_dagger^T
+// (adil.py:542 recomputes them from the z that adil.py:554-555 just wrote).  The z-step holds the freshly updated z tile
+// in registers and the D_dagger slice of the same 128 pixels in LDS, so the separate contraction launch — its re-read of
+// z (B P 4 bytes: 308 MB at 512 images) and of D_dagger — disappears from the loop.
+//
+// The contraction reduces over PIXELS, so its result is a sum over all slices: a workgroup therefore owns fixed ROWS
+// (8 waves x RB blocks of 32) and WALKS a contiguous range of slices with the (32 rows x AT*32 atoms) accumulators of its
+// blocks resident across the range, like grad_v_f32_kernel; it leaves one slab of partial sums per workgroup, summed by
+// adil_pack_codes in the fixed slab_sum order (bitwise reproducible, no atomics).  Rows beyond one workgroup's
+// 256 RB go to blockIdx.y and land in the same slab (disjoint rows), so the slab layout is [gridDim.x][Bp][K] for any B.
+//
+// MFMA operands of the new contraction: z_new sits in the C layout of the gz tiles (lane = pixel quad, registers = rows)
+// and is needed in the A layout (lane = row, 8 consecutive reduction indices), i.e. transposed: each wave passes it
+// through a private fp32 LDS image of 16 rows x 128 columns — half a block at a time, which is what fits next to the
+// D_dagger planes; the half's rows occupy their own 16 lanes of the A fragment, the other 16 lanes supply zeros (the
+// matrix pipe is idle most of the time in this kernel, LDS space is what is scarce).  Image column j = t*32 + c holds
+// pixel 4c + t — the row order of the LDS slice — so that a k-group of 16 image columns meets 16 consecutive LDS rows of
+// the slice, which come out as the B fragment (lane = atom, 8 consecutive pixels) of a transposing read
+// (ds_read_b64_tr_b16, one per plane and half fragment) — the same planes the gz contraction reads row-wise.
+// z fragments are split into their three bf16 pieces after the read (each element is read exactly once).
+// =========================================================================================================== //
+#define ZC_IS 132                                               // image row stride (floats): 128 + 4, rows shift by 4 banks
+// LDS row stride of the D_dagger planes is a COMPILE-TIME constant here (atoms padded to the tile count's maximum that
+// still fits: 32, 64, 112): with a run-time stride hipcc keeps one address register per (k-group, plane) of the
+// transposing reads — ~50 VGPRs of loop invariants, and the kernel spilled.
+template <int AT> struct ZCodes { static constexpr int KP = AT == 4 ? 112 : AT * 32, KS = KP + DPAD; };
+
+template <int AT, int RB>
+__global__ __launch_bounds__(512) void zstep_codes_kernel(float* __restrict__ z, float* __restrict__ m,
+                                                         float* __restrict__ sq, const float* __restrict__ d,
+                                                         const float* __restrict__ vp, float* __restrict__ slab, int B,
+                                                         int Bp, int P, int K, int Kp, AdamWHyper hy, float lo, float hi,
+                                                         float* max_abs_delta, int nslices, int spw,
+                                                         const float* skip_if_below, float skip_threshold, float* clear,
+                                                         const float* __restrict__ dyn) {
+    if (dyn != nullptr) { hy.step_size = dyn[0]; hy.bc2_sqrt = dyn[1]; }
+    using M = Mma<float>;
+    using Frag = M::Frag;
+    using DI = DImg<float>;
+    using BP = BufPx<float>;
+    constexpr int NWV = 8, KP = ZCodes<AT>::KP, Ks = ZCodes<AT>::KS, plane = SYNTH_TILE * Ks;
+    const bool first = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+    // device-side stop test, as in zstep_mfma_kernel.  A skipped launch leaves the slabs alone: they still hold the codes
+    // of the converged z, which is what every later pack_codes (and the final synthesis) has to see.
+    if (skip_if_below != nullptr && *skip_if_below < skip_threshold) {
+        if (max_abs_delta != nullptr && first) *max_abs_delta = 0.0f;
+        return;
+    }
+    if (clear != nullptr && first) *clear = 0.0f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sd = reinterpret_cast<bf16_t*>(smem_raw);            // [3][128][Ks] bf16: the h, m, l planes of D_dagger
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* img = reinterpret_cast<float*>(sd + 3 * plane) + w * 16 * ZC_IS;      // this wave's [16][ZC_IS] image
+    const int NG = Kp >> 4;                                       // k-groups of the packed codes (Kp <= KP)
+    const int s0 = blockIdx.x * spw, s1 = min(nslices, s0 + spw);
+    const int wrow0 = (blockIdx.y * NWV + w) * RB * 32;          // first row of this wave's RB blocks
+    const unsigned rowb = (unsigned)P * 4u;
+
+    // accv[0] = the accumulators of the block being processed, accv[1] = the other block's (RB = 2): the block loop stays
+    // ROLLED and the two sets trade places after every block — unrolled, the per-block address invariants of the second
+    // block were what no longer fitted the register file (reloaded from scratch at every block start).
+    f32x16 accv[RB][AT];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int at = 0; at < AT; ++at)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accv[rb][at][r] = 0.0f;
+    float dmax = 0.0f;
+
+    for (int s = s0; s < s1; ++s) {
+        const int p0 = s * SYNTH_TILE;
+        if (s > s0) __syncthreads();                              // everyone is done with the previous slice
+        fill_dict_slice<float, true, NWV * 64>(d, sd, p0, P, K, KP, Ks, tid);
+        __syncthreads();
+        const int voff = (int)((unsigned)(4 * h) * rowb) + (p0 + 4 * c) * 4;
+#pragma unroll 1
+        for (int rb = 0; rb < RB; ++rb) {
+            const int b0 = wrow0 + rb * 32;
+            if (b0 < Bp) {                                        // wave-uniform; no barrier inside
+                const int rows = B - b0 < 32 ? B - b0 : 32;
+                const unsigned bytes = (unsigned)rows * rowb;
+                const buf_rsrc rz = block_rsrc(z + (size_t)b0 * P, bytes), rm = block_rsrc(m + (size_t)b0 * P, bytes),
+                               rs = block_rsrc(sq + (size_t)b0 * P, bytes);
+                constexpr int GR = 2;                            // rows per group (see zstep_mfma_kernel)
+                BP::Raw zr[2][GR], mr[2][GR], sr[2][GR];
+#pragma unroll
+                for (int j = 0; j < GR; ++j) {
+                    const int soff = (int)((unsigned)c_row(j, 0) * rowb);
+                    zr[0][j] = BP::load(rz, voff, soff); mr[0][j] = BP::load(rm, voff, soff); sr[0][j] = BP::load(rs, voff, soff);
+                }
+                f32x16 acc[4];                                    // gz = (dL/dv) D_dagger of this block and slice
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+                const float* arow = vp + (size_t)(b0 + c) * Kp + 8 * h;
+                Frag a = frag_from_f32x8<float>(arow);
+#pragma unroll
+                for (int g = 0; g < KP / 16; ++g) {
+                    if (g < NG) {                                 // uniform
+                        const Frag an = frag_from_f32x8<float>(arow + 16 * ((g + 1 < NG) ? g + 1 : g));
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) M::mma(acc[t], a, DI::load8(sd + (t * 32 + c) * Ks + 16 * g + 8 * h, plane));
+                        a = an;
+                    }
+                }
+#pragma unroll
+                for (int grp = 0; grp < 16 / GR; ++grp) {
+                    const int cur = grp & 1, nxt = cur ^ 1;
+                    if (grp + 1 < 16 / GR) {
+#pragma unroll
+                        for (int j = 0; j < GR; ++j) {
+                            const int soff = (int)((unsigned)c_row(GR * (grp + 1) + j, 0) * rowb);
+                            zr[nxt][j] = BP::load(rz, voff, soff); mr[nxt][j] = BP::load(rm, voff, soff);
+                            sr[nxt][j] = BP::load(rs, voff, soff);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);           // keep the next group's requests ahead of this group's use
+#pragma unroll
+                    for (int j = 0; j < GR; ++j) {
+                        const int reg = GR * grp + j;
+                        const int soff = (int)((unsigned)c_row(reg, 0) * rowb);
+                        float zv[4], mv[4], sv[4];
+                        BP::unpack(zr[cur][j], zv); BP::unpack(mr[cur][j], mv); BP::unpack(sr[cur][j], sv);
+                        dmax = fmaxf(dmax, zstep_quad(zv, mv, sv, acc, reg, hy, lo, hi));
+                        BP::store(rz, voff, soff, zv); BP::store(rm, voff, soff, mv); BP::store(rs, voff, soff, sv);
+                        float* irow = img + (c_row(reg, h) & 15) * ZC_IS + c;    // z_new -> image row of its half, column t*32 + c
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) irow[t * 32] = zv[t];
+                    }
+                    if ((grp & 3) == 3) {
+                        // rows 16*hf .. 16*hf+15 of the block are complete in the image: v' += z_new D_dagger^T for them.
+                        // LDS executes a wave's instructions in order, so these reads see the writes above and the next
+                        // half's writes land behind them; the compiler is kept from reordering by the clobbers.
+                        const int hf = grp >> 2;
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        const float keep = ((c >> 4) == hf) ? 1.0f : 0.0f;
+                        const float* ar = img + (c & 15) * ZC_IS + 8 * h;
+#pragma unroll
+                        for (int kg = 0; kg < SYNTH_TILE / 16; ++kg) {
+                            const float4 q0 = *reinterpret_cast<const float4*>(ar + 16 * kg),
+                                         q1 = *reinterpret_cast<const float4*>(ar + 16 * kg + 4);
+                            const float f[8] = {q0.x * keep, q0.y * keep, q0.z * keep, q0.w * keep,
+                                                q1.x * keep, q1.y * keep, q1.z * keep, q1.w * keep};
+                            const Frag za = M::from8(f);
+#pragma unroll
+                            for (int at = 0; at < AT; ++at) {
+                                Frag db;
+                                db.h = ColFrag<bf16_t>::load(sd, Ks, 16 * kg, at * 32, lane);
+                                db.m = ColFrag<bf16_t>::load(sd + plane, Ks, 16 * kg, at * 32, lane);
+                                db.l = ColFrag<bf16_t>::load(sd + 2 * plane, Ks, 16 * kg, at * 32, lane);
+                                M::mma(accv[0][at], za, db);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);   // one k-group at a time: hoisted reads of later ones cost registers
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+                }
+            }
+            if constexpr (RB == 2) {                              // the other block's accumulators become the current ones
+#pragma unroll
+                for (int at = 0; at < AT; ++at)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float t = accv[0][at][r];
+                        accv[0][at][r] = accv[1][at][r];
+                        accv[1][at][r] = t;
+                    }
+            }
+        }
+    }
+    // (after a whole number of slices accv[0] is block 0's again: two trades per slice, also for blocks beyond the batch)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {                             // partial sums of this workgroup: slab[blockIdx.x][row][atom < K]
+        const int b0 = wrow0 + rb * 32;
+        if (b0 < Bp) {
+            float* dst = slab + (size_t)blockIdx.x * Bp * K;
+#pragma unroll
+            for (int at = 0; at < AT; ++at)
+                if (at * 32 + c < K) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[(size_t)(b0 + c_row(r, h)) * K + at * 32 + c] = accv[rb][at][r];
+                }
+        }
+    }
+    if (max_abs_delta != nullptr) {
+        dmax = wave_max(dmax);
+        if (lane == 0 && dmax > 0.0f) atomic_max_nonneg(max_abs_delta, dmax);
+    }
+}
+
+// =========================================================================================================== //
 // K7  Gram matrix D^T D (adil.py:523), K x K, fp32-grade on the bf16 matrix pipe.  The D tile of 32 pixels is staged
 // exactly as in grad_v_f32_kernel (transposed, three bf16 planes, [atom][pixel]) — and serves as BOTH MFMA operands: the
 // fragments of atom tile i (lane = atom, 8 consecutive pixels) against those of atom tile j.  8 waves share the AT x AT
@@ -2323,6 +2518,71 @@ static int launch_zstep_range(float* z, float* m, float* sq, const float* d, con
                        max_abs_delta, tile0, skip_if_below, skip_threshold, clear, dyn);
     ADIL_CHECK_LAUNCH();
     return 0;
+}
+
+// ---- K8 + K6: z-step that also leaves the next iteration's codes as slabs (zstep_codes_kernel) ---------------------- //
+// Shapes the fused kernel takes: whole 128-pixel slices, 16-byte aligned rows addressable with 32-bit offsets, and an
+// atom count whose D_dagger planes leave room for the eight 16 x 128 fp32 images in LDS (Kp <= 112).
+static inline bool zstep_codes_shape_ok(int B, int P, int K) {
+    return B > 0 && K > 0 && round_up(K, 16) <= 112 && P > 0 && P % SYNTH_TILE == 0 && P <= (1 << 23);
+}
+static inline void zstep_codes_grid(int P, int* nslices, int* spw, int* nwg) {
+    *nslices = P / SYNTH_TILE;
+    *spw = (*nslices + num_cu() - 1) / num_cu();
+    *nwg = (*nslices + *spw - 1) / *spw;
+}
+
+extern "C" size_t adil_zstep_codes_slab_bytes(int B, int P, int K) {
+    if (!zstep_codes_shape_ok(B, P, K)) return 0;
+    int nslices, spw, nwg;
+    zstep_codes_grid(P, &nslices, &spw, &nwg);
+    return (size_t)nwg * round_up(B, 32) * K * sizeof(float);
+}
+
+template <int AT, int RB>
+static int launch_zstep_codes(float* z, float* m, float* sq, const float* d, const float* vp, float* slab, int B, int P, int K,
+                              AdamWHyper hy, float lo, float hi, float* max_abs_delta, const float* skip_if_below,
+                              float skip_threshold, float* clear, const float* dyn, int* nslabs_out, hipStream_t st) {
+    const int Kp = round_up(K, 16), Bp = round_up(B, 32);
+    int nslices, spw, nwg;
+    zstep_codes_grid(P, &nslices, &spw, &nwg);
+    const size_t lds = (size_t)3 * SYNTH_TILE * ZCodes<AT>::KS * sizeof(bf16_t) + (size_t)8 * 16 * ZC_IS * sizeof(float);
+    int rc = set_lds((const void*)zstep_codes_kernel<AT, RB>, lds);
+    if (rc) return rc;
+    const int rows_per_wg = 8 * RB * 32, ny = (Bp + rows_per_wg - 1) / rows_per_wg;
+    hipLaunchKernelGGL((zstep_codes_kernel<AT, RB>), dim3(nwg, ny), dim3(512), lds, st, z, m, sq, d, vp, slab, B, Bp, P, K, Kp, hy,
+                       lo, hi, max_abs_delta, nslices, spw, skip_if_below, skip_threshold, clear, dyn);
+    ADIL_CHECK_LAUNCH();
+    *nslabs_out = nwg;
+    return 0;
+}
+
+extern "C" int adil_zstep_codes(float* z, float* m, float* s, const float* dpinv_t, const float* gvp, int B, int P, int K,
+                                float decay, float b1, float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi,
+                                float* max_abs_delta, const float* skip_if_below, float skip_threshold, float* clear,
+                                const float* dyn_scalars, float* code_slabs, size_t code_slab_bytes, int* nslabs_out,
+                                void* stream) {
+    ADIL_ENTER();
+    if (!z || !m || !s || !dpinv_t || !gvp || !code_slabs || !nslabs_out || B <= 0 || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS)
+        return ADIL_EINVAL;
+    *nslabs_out = 0;
+    if (!zstep_codes_shape_ok(B, P, K)) return ADIL_EINVAL;
+    if ((((uintptr_t)z | (uintptr_t)m | (uintptr_t)s | (uintptr_t)dpinv_t | (uintptr_t)code_slabs) % 16) != 0) return ADIL_EINVAL;
+    if (code_slab_bytes < adil_zstep_codes_slab_bytes(B, P, K)) return ADIL_EWORKSPACE;
+    AdamWHyper hy{decay, b1, b2, eps, step_size, bc2_sqrt};
+    hipStream_t st = (hipStream_t)stream;
+    const int at = atom_tiles(K), Bp = round_up(B, 32);
+    // accumulators per wave: RB blocks x AT atom tiles <= 4 (64 registers).  One block per wave when the batch leaves the
+    // second one empty anyway.
+    if (at == 1) {
+        if (Bp > 256) return launch_zstep_codes<1, 2>(z, m, s, dpinv_t, gvp, code_slabs, B, P, K, hy, lo, hi, max_abs_delta, skip_if_below, skip_threshold, clear, dyn_scalars, nslabs_out, st);
+        return launch_zstep_codes<1, 1>(z, m, s, dpinv_t, gvp, code_slabs, B, P, K, hy, lo, hi, max_abs_delta, skip_if_below, skip_threshold, clear, dyn_scalars, nslabs_out, st);
+    }
+    if (at == 2) {
+        if (Bp > 256) return launch_zstep_codes<2, 2>(z, m, s, dpinv_t, gvp, code_slabs, B, P, K, hy, lo, hi, max_abs_delta, skip_if_below, skip_threshold, clear, dyn_scalars, nslabs_out, st);
+        return launch_zstep_codes<2, 1>(z, m, s, dpinv_t, gvp, code_slabs, B, P, K, hy, lo, hi, max_abs_delta, skip_if_below, skip_threshold, clear, dyn_scalars, nslabs_out, st);
+    }
+    return launch_zstep_codes<4, 1>(z, m, s, dpinv_t, gvp, code_slabs, B, P, K, hy, lo, hi, max_abs_delta, skip_if_below, skip_threshold, clear, dyn_scalars, nslabs_out, st);
 }
 
 extern "C" int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, const float* gvp, int B, int P, int K,

@@ -489,7 +489,7 @@ static inline int stream_grid(size_t work_items, int per_block) {
     return (int)b;
 }
 
-extern "C" int adil_abi_version(void) { return 6; }
+extern "C" int adil_abi_version(void) { return 7; }
 extern "C" int adil_max_atoms(void) { return ADIL_MAX_ATOMS; }
 
 extern "C" int adil_pack_codes(const float* v, const int64_t* index, int B, int K, float* vp, int32_t* pos, void* vpt,

@@ -408,7 +408,8 @@ class DDragueSolver:
     the same shape (so a captured graph serves every batch of an evaluation)."""
 
     def __init__(self, model, images: Tensor, d: Tensor, eps: float, loss: str = "ce", targeted: bool = False,
-                 kappa: float = 50.0, pinv: Optional[PseudoInverse] = None, labels: Optional[Tensor] = None):
+                 kappa: float = 50.0, pinv: Optional[PseudoInverse] = None, labels: Optional[Tensor] = None,
+                 fuse_codes: bool = True):
         self.model, self.images, self.d = model, _flat_images(images).clone(), d
         self.b = self.images.shape[0]
         self.eps, self.loss, self.kappa = float(eps), loss, float(kappa)
@@ -421,6 +422,15 @@ class DDragueSolver:
         self.stop = ops.StopTest(self.images.device, 1e-6)                               # adil.py:559, on the device
         self.iters = 0
         self._graph = None
+        # The codes v = z D_dagger^T of the NEXT iteration come out of the z-step itself (ops.zstep_codes_, round 4): the
+        # kernel contracts the z tile it has just updated against the D_dagger slice it holds in LDS anyway, and leaves
+        # per-workgroup partial sums in this buffer for pack_codes — the separate contraction launch and its second pass
+        # over z are gone from the loop.  `_vnext`: None = z is still all zero (so are its codes), else the SlabGrad of
+        # the last z-step.  Shapes the fused kernel does not take (ragged pixel count, K > 112) keep the two launches.
+        p, k = ops.dict_shape(d)
+        nbytes = ops.zstep_codes_slab_bytes(self.b, p, k) if (fuse_codes and self.b > 0) else 0
+        self._vslabs = torch.empty(nbytes, dtype=torch.uint8, device=self.z.device) if nbytes else None
+        self._vnext = None
 
     def reset(self, images: Tensor, labels: Optional[Tensor] = None) -> "DDragueSolver":
         """Same buffers, next batch (same shape and dtype): z, moments, step counter and stop slots back to their start."""
@@ -430,25 +440,41 @@ class DDragueSolver:
             t.zero_()
         self.sched.t, self.iters = 0, 0
         self.stop.reset()
+        self._vnext = None
         return self
 
     def codes(self, defer: bool = False):
-        """v = z D_dagger^T (K6, adil.py:542).  defer: for pack_codes only — possibly still as partial sums (ops.SlabGrad)."""
+        """v = z D_dagger^T (K6, adil.py:542) as its own contraction.  defer: for pack_codes only — possibly still as
+        partial sums (ops.SlabGrad)."""
         _, vcode = ops.grad(self.z, self.dpt, None, self.b, want_d=False, want_v=True, defer_v=defer)
         return vcode
+
+    def packed_codes(self) -> Tensor:
+        """The codes of the current z, packed for the synthesis: from the last z-step's slabs when it produced them."""
+        if self._vslabs is None:
+            return ops.pack_codes(self.codes(defer=True), None, self.b)
+        if self._vnext is None:                                  # no z-step yet: z = 0 (adil.py:530), so v = 0
+            p, k = ops.dict_shape(self.d)
+            return torch.zeros(ops._round_up(self.b, 32), ops._round_up(k, 16), dtype=torch.float32, device=self.z.device)
+        return ops.pack_codes(self._vnext, None, self.b)
 
     def iterate(self, dyn: Optional[Tensor] = None) -> None:
         """One iteration.  The stop test of adil.py:559 runs on the device (ops.StopTest): after the iteration whose
         max|dz| falls below 1e-6 the z-step launches do nothing; `self.stop.converged()` polls it."""
         b = self.b
         self.iters += 1
-        vp = ops.pack_codes(self.codes(defer=True), None, b)                             # adil.py:542
+        vp = self.packed_codes()                                                         # adil.py:542
         xt = ops.synth(self.images, self.d, vp, b)                                       # adil.py:543-544
         _, _, g = input_gradient(self.model, xt, self.labels, self.loss, self.coeff, self.kappa, "mean")
         _, gv = ops.grad(g, self.d, None, b, want_d=False, want_v=True, defer_v=True)    # dL/dv = g D (summed by pack_codes)
         # dL/dz = (dL/dv) D_dagger is formed inside the kernel and consumed by AdamW(z) + clamp: never materialised (K8)
-        ops.zstep_(self.z, self.m, self.s, self.dpt, ops.pack_codes(gv, None, b), b, self.sched.next(), -self.eps,
-                   self.eps, stop=self.stop, dyn=dyn)
+        gvp = ops.pack_codes(gv, None, b)
+        if self._vslabs is not None:
+            self._vnext = ops.zstep_codes_(self.z, self.m, self.s, self.dpt, gvp, b, self.sched.next(), -self.eps, self.eps,
+                                           self._vslabs, stop=self.stop, dyn=dyn)
+        else:
+            ops.zstep_(self.z, self.m, self.s, self.dpt, gvp, b, self.sched.next(), -self.eps, self.eps, stop=self.stop,
+                       dyn=dyn)
 
     # -- three iterations as ONE hipGraph launch ------------------------------------------------------------------ #
     def _capture(self) -> None:
@@ -506,17 +532,19 @@ class DDragueSolver:
         return self
 
     def result(self) -> Tuple[Tensor, Tensor]:
-        vcode = self.codes()
-        adv = ops.synth(self.images, self.d, ops.pack_codes(vcode, None, self.b), self.b, pixel_clamp=True)   # :563-567
-        return adv, vcode
+        vp = self.packed_codes()
+        adv = ops.synth(self.images, self.d, vp, self.b, pixel_clamp=True)               # adil.py:563-567
+        return adv, vp[:self.b, :ops.dict_shape(self.d)[1]].contiguous()
 
 
 def solve_ddrague(model, images: Tensor, d: Tensor, eps: float, steps_inference: int = 30, loss: str = "ce",
                   targeted: bool = False, kappa: float = 50.0, pinv: Optional[PseudoInverse] = None,
-                  labels: Optional[Tensor] = None, return_trace: bool = False, use_graph: bool = False):
+                  labels: Optional[Tensor] = None, return_trace: bool = False, use_graph: bool = False,
+                  fuse_codes: bool = True):
     """forward_supervised_DDrague (adil.py:508-567): optimise z (B,C,H,W) with AdamW(1e-2), the perturbation
     being D D_dagger z; z is clamped to +-eps (the perturbation itself is not — quirk Q6)."""
-    solver = DDragueSolver(model, images, d, eps, loss, targeted, kappa, pinv, labels).run(steps_inference, use_graph)
+    solver = DDragueSolver(model, images, d, eps, loss, targeted, kappa, pinv, labels, fuse_codes).run(steps_inference,
+                                                                                                       use_graph)
     adv, vcode = solver.result()
     if return_trace:
         return adv, dict(z=solver.z, v=vcode, iters=solver.iters, labels=solver.labels)

@@ -385,6 +385,36 @@ def zstep_(z: Tensor, m: Tensor, s: Tensor, dpinv_t: Tensor, gvp: Tensor, batch:
                "adil_zstep")
 
 
+def zstep_codes_slab_bytes(batch: int, p: int, k: int) -> int:
+    """Bytes of the slab buffer zstep_codes_ needs for this shape; 0 = the fused kernel does not take it (whole 128-pixel
+    slices, K <= 112): use zstep_ and a separate ops.grad(z, D_dagger^T) then."""
+    return int(_lib.load().adil_zstep_codes_slab_bytes(int(batch), int(p), int(k)))
+
+
+def zstep_codes_(z: Tensor, m: Tensor, s: Tensor, dpinv_t: Tensor, gvp: Tensor, batch: int, h: AdamWScalars, lo: float,
+                 hi: float, slabs: Tensor, stop: Optional[StopTest] = None, dyn: Optional[Tensor] = None) -> "SlabGrad":
+    """zstep_ that also contracts the freshly updated z with D_dagger^T: returns the NEXT iteration's codes
+    v' = z_new D_dagger^T (adil.py:542) as a SlabGrad living in `slabs` (a uint8 buffer of zstep_codes_slab_bytes that
+    the caller owns — it must outlive the SlabGrad, which pack_codes sums).  A launch skipped by the device-side stop
+    test leaves the slabs as they were, i.e. the codes of the converged z."""
+    lib = _lib.load()
+    for name, t in (("z", z), ("m", m), ("s", s), ("dpinv_t", dpinv_t), ("gvp", gvp)):
+        _dev(t, name, torch.float32)
+    _dev(slabs, "slabs", torch.uint8)
+    p, k = dict_shape(dpinv_t)
+    if not (z.numel() == m.numel() == s.numel() == batch * p) or gvp.shape != (_round_up(batch, 32), _round_up(k, 16)):
+        raise ValueError("zstep_codes_: operand shapes do not match (B, P, K)")
+    need = zstep_codes_slab_bytes(batch, p, k)
+    if need == 0 or slabs.numel() < need:
+        raise ValueError("zstep_codes_: shape not supported by the fused kernel, or slab buffer too small")
+    dmax, skip, thr, clear = _stop_args(None, stop)
+    nslabs = c_int(0)
+    _lib.check(lib.adil_zstep_codes(_ptr(z), _ptr(m), _ptr(s), _ptr(dpinv_t), _ptr(gvp), batch, p, k, h.decay, h.b1, h.b2,
+                                    h.eps, h.step_size, h.bc2_sqrt, float(lo), float(hi), dmax, skip, thr, clear, _ptr(dyn),
+                                    _ptr(slabs), slabs.numel(), byref(nslabs), _stream()), "adil_zstep_codes")
+    return SlabGrad(slabs, slabs.data_ptr(), nslabs.value, _round_up(batch, 32), batch, k)
+
+
 def adamw_l1ball_(v: Tensor, grad_vb, pos: Optional[Tensor], m: Tensor, s: Tensor, h: AdamWScalars,
                   radius: float, max_abs_delta: Optional[Tensor] = None, reset_pos: bool = False,
                   stop: Optional[StopTest] = None, dyn: Optional[Tensor] = None) -> None:

@@ -44,7 +44,8 @@ extern "C" {
  * entry points incl. adil_zstep (hipGraph replay of the learning step and of the inference iterations).  6: the two
  * helper launches of a gradient pass moved into their neighbours — adil_pack_codes can emit the transposed codes that
  * adil_grad needs (`vpt`) and can take its rows from the grad_v partial sums ("slabs") of a preceding adil_grad;
- * adil_grad can leave the reduction of those slabs to its consumer (`nslabs_out`); adil_adamw_l1ball consumes them. */
+ * adil_grad can leave the reduction of those slabs to its consumer (`nslabs_out`); adil_adamw_l1ball consumes them.
+ * 7: adil_zstep_codes — the z-step of a DDrague iteration also produces the next iteration's codes (as slabs). */
 int adil_abi_version(void);
 
 /* Largest K (atoms) the kernels support. */
@@ -142,6 +143,21 @@ int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, float* s, s
 int adil_zstep(float* z, float* m, float* s, const float* dpinv_t, const float* gvp, int B, int P, int K, float decay,
                float b1, float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi, float* max_abs_delta,
                const float* skip_if_below, float skip_threshold, float* clear, const float* dyn_scalars, void* stream);
+
+/* adil_zstep that ALSO leaves the codes of the next iteration, v' = z_new D_dagger^T (adil.py:542, recomputed by the
+ * reference from the z that adil.py:554-555 just wrote), as per-workgroup partial sums in `code_slabs`: *nslabs_out slabs
+ * of [roundup(B,32)][K] fp32 — the layout adil_grad leaves behind, summed by adil_pack_codes(slabs, nslabs, slab_rows =
+ * roundup(B,32)).  The separate contraction launch of a DDrague iteration (adil_grad with g := z: a second pass over z and
+ * D_dagger) disappears; the z tile is contracted while it is still in registers, against the D_dagger slice the z-step
+ * holds in LDS anyway.  Same arithmetic for z, m, s and the stop test as adil_zstep (bitwise).  A launch skipped by the
+ * device-side stop test leaves code_slabs untouched: they keep the codes of the converged z.
+ * Shapes: P a multiple of 128 (and < 2^23), K <= 112, 16-byte aligned pointers; adil_zstep_codes_slab_bytes returns the
+ * size code_slabs must have, 0 when the shape is not supported (use adil_zstep + adil_grad then). */
+size_t adil_zstep_codes_slab_bytes(int B, int P, int K);
+int adil_zstep_codes(float* z, float* m, float* s, const float* dpinv_t, const float* gvp, int B, int P, int K, float decay,
+                     float b1, float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi, float* max_abs_delta,
+                     const float* skip_if_below, float skip_threshold, float* clear, const float* dyn_scalars,
+                     float* code_slabs, size_t code_slab_bytes, int* nslabs_out, void* stream);
 
 /* Fused AdamW step on ALL N rows of the code matrix + row-wise l1-ball projection.
  * The gradient is non-zero only for the rows of the current batch: pos[n] = b if row n is

@@ -234,14 +234,18 @@ def _input_grad(model, xt: Tensor, labels: Tensor, loss: str, coeff: float, kapp
 
 
 def learn_step_a(model, x: Tensor, index: Tensor, d: Tensor, v: Tensor, opt_d: AdamWState, opt_v: AdamWState,
-                 eps: float, loss: str, coeff: float, kappa: float):
+                 eps: float, loss: str, coeff: float, kappa: float, labels: Optional[Tensor] = None):
     """One hot-loop iteration of learn_dictionary_a (adil.py:168-191):
     pseudo-labels, synth, classifier fwd/bwd, AdamW on (d, ALL rows of v),
     l1-ball projection of all rows of v, clamp of d to [-1,1].
     d, v and the optimiser states are updated in place.
-    Returns (loss value, #fooled measured at the pre-update iterate)."""
-    with torch.no_grad():
-        label = model(x).argmax(dim=-1)                                   # adil.py:172
+    Returns (loss value, #fooled measured at the pre-update iterate).
+    labels: None = the reference's sequence (recomputed here, adil.py:172); given = the same values handed in by a
+    caller that keeps them (the constant-label cache SURVEY.md quirk Q4 allows; bench.py times both policies)."""
+    label = labels
+    if label is None:
+        with torch.no_grad():
+            label = model(x).argmax(dim=-1)                               # adil.py:172
     xt = synth(x, d, v[index])                                            # adil.py:176 -> :25-26
     out, ls, g = _input_grad(model, xt, label, loss, coeff, kappa, "sum")  # adil.py:179-185
     fooled = int((out.argmax(dim=-1) != label).sum())                     # adil.py:177

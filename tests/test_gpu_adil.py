@@ -721,6 +721,51 @@ def test_graphed_ddrague_is_bit_identical(tmp_path):
     assert torch.equal(e.result()[0], gr.result()[0]) and gr.stop.converged() and e.iters <= 4 and gr.iters <= 6
 
 
+def test_ddrague_codes_from_the_zstep_match_the_separate_contraction():
+    """Round 4: the codes v = z D_dagger^T of every iteration after the first come out of the preceding z-step
+    (adil_zstep_codes) instead of a contraction launch of their own.  Both routes compute the same fp32-grade sums in a
+    different order, so the two solvers agree to accumulated rounding: adversarial images within 2e-5, identical label
+    decisions, the same iteration count; the fused route never launches the separate contraction (counted)."""
+    from dl_attack_on_imagenet_amd import engine, ops
+    from tinynet import make_tinynet
+    net = make_tinynet(6).to(DEV)
+    g = torch.Generator().manual_seed(23)
+    d = (-1 + 2 * torch.rand(3, 32, 32, 6, generator=g)).to(DEV)
+    x = torch.rand(40, 3, 32, 32, generator=g).to(DEV)
+    calls = {"grad_on_z": 0}
+    real_grad = ops.grad
+
+    def counting_grad(gq, dq, *a, **kw):
+        if gq.dtype == torch.float32 and gq.shape == x.shape and dq.data_ptr() == solver.dpt.data_ptr():
+            calls["grad_on_z"] += 1
+        return real_grad(gq, dq, *a, **kw)
+
+    pinv = engine.PseudoInverse(d)
+    solver = engine.DDragueSolver(net, x, d, 0.1, "logits", pinv=pinv)
+    assert solver._vslabs is not None
+    ops.grad = counting_grad
+    try:
+        solver.run(12)
+        adv_f, v_f = solver.result()
+    finally:
+        ops.grad = real_grad
+    assert calls["grad_on_z"] == 0
+    two = engine.DDragueSolver(net, x, d, 0.1, "logits", pinv=pinv, fuse_codes=False).run(12)
+    adv_t, v_t = two.result()
+    assert two._vslabs is None and solver.iters == two.iters == 12
+    assert float((adv_f - adv_t).abs().max()) <= 2e-5 and float((v_f - v_t).abs().max()) <= 2e-5
+    assert torch.equal(net(adv_f).argmax(-1), net(adv_t).argmax(-1))
+    # no iteration at all: z = 0, the codes are zero, the result is the clamped clean batch
+    fresh = engine.DDragueSolver(net, x, d, 0.1, "logits", pinv=pinv)
+    adv0, v0 = fresh.result()
+    assert torch.equal(adv0, x.clamp(0, 1)) and not bool(v0.any())
+    # reset() re-arms the zero-codes state for the next batch
+    solver.reset(x[:40])
+    assert solver._vnext is None
+    solver.run(12)
+    assert torch.equal(solver.result()[0], adv_f)
+
+
 @pytest.mark.parametrize("graph", [1, 0])
 def test_main_cli_one_image_attack(graph, tmp_path, monkeypatch):
     """main.py end to end (the reference's one-image demo, main.py:29-100): default classifier (mobilenet_v2), the
@@ -920,7 +965,9 @@ def test_bench_transfer_mode_line(tmp_path):
     # (4 images, 10 atoms) every kernel is launch latency and the two contractions of an iteration (`grad`: z D_dagger^T and
     # g D, two launches each iteration) can add up to more than the one z-step launch
     kern = line["roofline"]["kernel"]
-    assert kern in ("zstep_", "grad") and line["roofline"]["launches_timed"] == 2 * 5 * (1 if kern == "zstep_" else 2)
+    # round 4: the z-step also produces the next iteration's codes, so an iteration has ONE contraction launch (`grad`: g D)
+    assert kern in ("zstep_codes_", "grad", "synth") and line["roofline"]["launches_timed"] == 2 * 5 + (2 if kern == "synth" else 0)
+    assert "grad[z D_dagger^T]" not in line["kernels_ms_per_launch"]
     assert line["config"]["ddrague_iterations_run_per_batch"] == 5
     # two ranks (one-GPU rehearsal: gloo, shared card): performance.py deals batch i to rank i % 2, each rank keeps only its
     # own batches resident, the final sums are all-reduced; the line says which backend it ran on
@@ -957,13 +1004,16 @@ def test_bench_inference_and_learn_mode_lines(tmp_path):
 
     inf = line("--mode", "inference")
     # the z-step at any real size; at 8 images x 10 atoms every launch is latency and any of the iteration's kernels can be slowest
-    assert inf["roofline"]["kernel"] in ("zstep_", "grad", "grad[z D_dagger^T]", "synth")
+    assert inf["roofline"]["kernel"] in ("zstep_codes_", "grad", "synth")
     assert inf["unit"] == "images/sec" and inf["n_gpus"] == 1 and inf["steps"] == 3
-    assert set(inf["kernels_ms_per_step"]) >= {"grad[z D_dagger^T]", "synth", "grad", "zstep_", "pack_codes"}
+    # round 4: no contraction launch for z D_dagger^T any more — the z-step leaves the next iteration's codes itself
+    assert set(inf["kernels_ms_per_step"]) >= {"synth", "grad", "zstep_codes_", "pack_codes"}
+    assert "grad[z D_dagger^T]" not in inf["kernels_ms_per_step"] and "zstep_" not in inf["kernels_ms_per_step"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in inf["roofline"]
     learn = line()
     assert "cached" in learn["config"]["workload"] and learn["value_cached_labels"] == learn["value"]
+    assert "BENCH_r02" in learn["value_definition"] and "cached" in learn["value_definition"]
     assert learn["value_reference_op_sequence_recomputed_labels"] == learn["config"]["recomputed_labels_variant"]["images_per_sec"]
     assert learn["config"]["collective"]["world_size"] == 1 and learn["config"]["collective"]["backend"] is None
     ref = line("--cache-labels", "0")

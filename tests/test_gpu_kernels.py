@@ -506,6 +506,73 @@ def test_zstep_fused_vs_unfused(shape):
     close(mf, st.m, 1e-5); close(sf, st.v, 1e-5)
 
 
+@pytest.mark.parametrize("shape", [(512, 3, 32, 32, 50), (500, 3, 16, 16, 64), (33, 3, 16, 16, 10), (300, 3, 16, 24, 100),
+                                   (600, 3, 16, 16, 50), (70, 3, 16, 8, 112), (16, 3, 224, 224, 50)])
+def test_zstep_codes_fused_with_next_codes(shape):
+    """adil_zstep_codes (ABI 7): the z-step that also contracts the updated z with D_dagger^T.  (i) z, m, s and max|dz| are
+    the bits of adil_zstep on the same inputs (same arithmetic, other workgroup shape); (ii) the codes pack_codes sums from
+    its slabs equal z_new D_dagger^T of an fp64 matmul to fp32-grade tolerance (the fixed-order slab sums make them
+    bitwise reproducible); (iii) a launch the device-side stop test skips leaves z AND the slabs untouched.  One / two
+    blocks per wave, ragged rows, a second row range of workgroups (600 rows), all three atom tilings, one and several
+    slices per workgroup (224 x 224: 1176 slices)."""
+    b, c, h, w, k = shape
+    o = ops()
+    p = c * h * w
+    gen = torch.Generator().manual_seed(sum(shape) + 11)
+    dpt = (torch.randn(c, h, w, k, generator=gen) * 0.1).to(DEV)
+    gv = torch.randn(b, k, generator=gen).to(DEV)
+    z0 = (torch.randn(b, c, h, w, generator=gen) * 0.01).to(DEV)
+    eps = 0.02
+    nbytes = o.zstep_codes_slab_bytes(b, p, k)
+    assert nbytes > 0
+    slabs = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    za, zb = z0.clone(), z0.clone()
+    ma, sa, mb, sb = (torch.zeros_like(z0) for _ in range(4))
+    sched_a, sched_b = o.AdamWSchedule(1e-2), o.AdamWSchedule(1e-2)
+    stop_a, stop_b = o.StopTest(DEV, 1e-6), o.StopTest(DEV, 1e-6)
+    for it in range(3):
+        gvp = o.pack_codes(gv * 0.5 ** it, None, b)
+        o.zstep_(za, ma, sa, dpt, gvp, b, sched_a.next(), -eps, eps, stop=stop_a)
+        vnext = o.zstep_codes_(zb, mb, sb, dpt, gvp, b, sched_b.next(), -eps, eps, slabs, stop=stop_b)
+        assert torch.equal(za, zb) and torch.equal(ma, mb) and torch.equal(sa, sb), it
+        assert torch.equal(stop_a.slots, stop_b.slots), it
+        assert isinstance(vnext, o.SlabGrad) and vnext.shape == (b, k) and vnext.nslabs >= 1
+        codes = o.pack_codes(vnext, None, b)
+        ref = zb.double().reshape(b, p) @ dpt.double().reshape(p, k)
+        close(codes[:b, :k], ref, 2e-6 * float(ref.abs().max()), f"codes it {it}")       # ~30 fp32 ulps of the largest entry
+        assert not bool(codes[b:].any()) and not bool(codes[:, k:].any())
+        assert torch.equal(codes, o.pack_codes(vnext, None, b))
+    # the contraction launch it replaces (another summation order, the same fp32-grade maths)
+    _, dense = o.grad(zb, dpt, None, b, want_d=False)
+    close(codes[:b, :k], dense, 4e-6 * float(ref.abs().max()), "vs adil_grad")
+    # a skipped launch: previous slot below the threshold -> nothing moves, the slabs keep the converged z's codes
+    stop_b.slots[(stop_b.t + 2) % 3] = 0.0
+    keep_z, keep_slabs = zb.clone(), slabs.clone()
+    o.zstep_codes_(zb, mb, sb, dpt, o.pack_codes(gv, None, b), b, sched_b.next(), -eps, eps, slabs, stop=stop_b)
+    assert torch.equal(zb, keep_z) and torch.equal(slabs, keep_slabs) and stop_b.converged()
+
+
+def test_zstep_codes_unsupported_shapes_are_refused():
+    """Shapes outside the fused kernel (pixel count not a multiple of 128, K > 112) report 0 slab bytes, and the entry
+    point itself answers ADIL_EINVAL instead of running; DDragueSolver then keeps the two-launch route."""
+    from dl_attack_on_imagenet_amd import engine
+    o = ops()
+    assert o.zstep_codes_slab_bytes(5, 3 * 7 * 9, 3) == 0 and o.zstep_codes_slab_bytes(40, 3 * 64 * 64, 128) == 0
+    assert o.zstep_codes_slab_bytes(40, 3 * 64 * 64, 112) > 0
+    z = torch.zeros(5, 3, 7, 9, device=DEV)
+    with pytest.raises(ValueError):
+        o.zstep_codes_(z, z.clone(), z.clone(), torch.zeros(3, 7, 9, 3, device=DEV), o.pack_codes(torch.zeros(5, 3, device=DEV), None, 5),
+                       5, o.AdamWSchedule(1e-2).next(), -1.0, 1.0, torch.empty(1024, dtype=torch.uint8, device=DEV))
+    from tinynet import make_tinynet
+    net = make_tinynet(3).to(DEV)
+    gen = torch.Generator().manual_seed(2)
+    d = (-1 + 2 * torch.rand(3, 7, 9, 3, generator=gen)).to(DEV)
+    solver = engine.DDragueSolver(net, torch.rand(5, 3, 7, 9, generator=gen).to(DEV), d, 0.1, "ce")
+    assert solver._vslabs is None
+    solver.run(3)
+    assert solver.result()[0].shape == (5, 3, 7, 9)
+
+
 @pytest.mark.parametrize("shape", [(5, 3, 7, 9, 3), (33, 3, 16, 16, 10), (64, 3, 20, 12, 50), (40, 3, 8, 8, 100), (70, 3, 32, 32, 128)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_synth_fp8_operands(shape, dt):
