@@ -11,6 +11,7 @@
 // 8 consecutive indices 16g + 8h + j, j = 0..7, of row/column r — identical for both instruction shapes, so the
 // data movement is shared and only Mma<T>::mma differs (6 split MFMAs vs 1 bf16 MFMA per k-group).
 // C/D layout of a 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 
@@ -899,9 +900,12 @@ __global__ __launch_bounds__(256) void grad_d_mfma_kernel(const T* __restrict__ 
 
 // D tile elements of one thread: consecutive threads -> consecutive atoms of one pixel (coalesced); the atom and
 // pixel tails are zeroed by a multiply (never a select on the loaded value)
+// (k0, kn): the atom window [k0, k0 + kn) this workgroup contracts against, of a dictionary with row stride K (the whole
+// dictionary by default; one half of it when two workgroups split the atoms of a K > 64 dictionary, see grad_fused_mfma_kernel)
 template <typename T, int AT, int NW, bool FAST>
 __device__ __forceinline__ void gv_load_d(const float* __restrict__ d, int tile, int P, int K, int tid,
-                                          float (&dreg)[(GV_TW * AT * 32 + NW * 64 - 1) / (NW * 64)]) {
+                                          float (&dreg)[(GV_TW * AT * 32 + NW * 64 - 1) / (NW * 64)], int k0 = 0, int kn = -1) {
+    if (kn < 0) kn = K;
     // RAW loads only (clamped addresses).  The 0/1 tail mask is applied in gv_write_d, one phase later: any use of
     // these values here would make hipcc wait for them right away, and vmcnt being in issue order that wait also
     // drains every load issued before them (the prefetched g block).
@@ -911,19 +915,20 @@ __device__ __forceinline__ void gv_load_d(const float* __restrict__ d, int tile,
         const int i = tid + e * NT;
         const int px = i / KA, a = i - px * KA;
         const int pix = tile * GV_TW + (px < GV_TW ? px : GV_TW - 1);
-        dreg[e] = d[(size_t)((FAST || pix < P) ? pix : P - 1) * K + (a < K ? a : K - 1)];
+        dreg[e] = d[(size_t)((FAST || pix < P) ? pix : P - 1) * K + k0 + (a < kn ? a : kn - 1)];
     }
 }
 template <typename T, int AT, int NW, bool FAST>
 __device__ __forceinline__ void gv_write_d(bf16_t* dst, int tile, int P, int K, int tid,
-                                           const float (&dreg)[(GV_TW * AT * 32 + NW * 64 - 1) / (NW * 64)]) {
+                                           const float (&dreg)[(GV_TW * AT * 32 + NW * 64 - 1) / (NW * 64)], int kn = -1) {
     constexpr int KA = AT * 32, NT = NW * 64, DPT = (GV_TW * KA + NT - 1) / NT, GD = GV_TW + DPAD;
+    if (kn < 0) kn = K;
 #pragma unroll
     for (int e = 0; e < DPT; ++e) {
         const int i = tid + e * NT;
         const int px = i / KA, a = i - px * KA;
         const int pix = tile * GV_TW + px;
-        const float m = (a < K && (FAST || pix < P)) ? 1.0f : 0.0f;   // atom / pixel tails: multiply, never a select
+        const float m = (a < kn && (FAST || pix < P)) ? 1.0f : 0.0f;   // atom / pixel tails: multiply, never a select
         if (px < GV_TW) DImg<T>::put(dst, a * GD + px, KA * GD, dreg[e] * m);
     }
 }
@@ -1077,7 +1082,23 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
                                                                   const typename Mma<T>::Elem* __restrict__ vpt,
                                                                   int vstride, float* __restrict__ grad_d,
                                                                   float* __restrict__ slab, int B, int Bp, int P, int K,
-                                                                  int tile_begin, int tile_end, int tiles_per_wg) {
+                                                                  int tile_begin, int tile_end, int tiles_per_wg,
+                                                                  int k_split, int nranges) {
+    // k_split > 0 (K > 64 on AT = 2 tiles): TWO workgroups share a tile range and split the ATOMS — [0, k_split) and
+    // [k_split, K) — instead of one workgroup holding all of them: a single workgroup with 128 atoms has room for 256 rows
+    // only (its grad_v accumulators), which made a 512-row batch two passes over D and grad_d or two passes over g.  Each
+    // half reads the whole g block (so g crosses the L2 twice) but only its own columns of D, writes its own columns of
+    // grad_d and of the range's slab: D, grad_d and the slabs move once.  The halves of a range sit 8 block ids apart,
+    // i.e. on the same XCD under the round-robin placement (speed only: the second reader of a g tile then finds it in
+    // that XCD's L2 instead of fetching it from HBM again).
+    int range = blockIdx.x, k0 = 0, kn = K;
+    if (k_split > 0) {
+        const int bid = blockIdx.x, half = (bid >> 3) & 1;
+        range = (bid >> 4) * 8 + (bid & 7);
+        if (range >= nranges) return;                             // whole workgroup, before any barrier
+        k0 = half ? k_split : 0;
+        kn = half ? K - k_split : k_split;
+    }
     // WV = false: the grad_d half alone (no D tile, no grad_v accumulators, no slab) — the LDS-staged grad_d kernel of
     // K > 64, where the direct-load kernel is left with 128-byte row pieces (finding 17) and the fused kernel with 256 rows.
     // NW waves, each owning RB consecutive 32-row batch blocks (RB = 2 keeps the 512-row workgroup at 8 waves, i.e.
@@ -1105,7 +1126,7 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
     E* simg = reinterpret_cast<E*>(sdt + (WV ? 2 * DBUF : 0));   // [NBLK][32][GS]  the g block of this tile
     float* red = reinterpret_cast<float*>(simg + NBLK * 32 * GS);   // [NW][16][64]  grad_d row-split partials
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
-    const int t0 = tile_begin + blockIdx.x * tiles_per_wg;
+    const int t0 = tile_begin + range * tiles_per_wg;
     const int t1 = min(tile_end, t0 + tiles_per_wg);
     const int ti = w % NTILE, ks = w / NTILE, tp = ti & 1, ta = ti >> 1;
 
@@ -1126,7 +1147,7 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
     for (int kg = 0; kg < NKG; ++kg) {
         const int r0 = ks * RS + 16 * kg;
         const int rr = (r0 < Bp) ? r0 : 0;                       // splits beyond the batch are skipped below
-        vfr[kg] = M::load8_raw(vpt + (size_t)(ta * 32 + c) * vstride + rr + 8 * h);
+        vfr[kg] = M::load8_raw(vpt + (size_t)(k0 + ta * 32 + c) * vstride + rr + 8 * h);
     }
     // Retire these loads BEFORE the tile loop.  hipcc's waitcnt insertion is path-insensitive: if the fragments could
     // still be in flight at the loop header it guards every use inside the loop with a counted vmcnt that, in steady
@@ -1137,11 +1158,11 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
     float dreg[DPT];
     u32x4 blk[RB][NLD];
     if (t0 < t1) {
-        if constexpr (WV) gv_load_d<T, AT, NW, FAST>(d, t0, P, K, tid, dreg);
+        if constexpr (WV) gv_load_d<T, AT, NW, FAST>(d, t0, P, K, tid, dreg, k0, kn);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
             if ((w * RB + rb) * 32 < Bp) gv_load_g<T, FAST>(g, t0, (w * RB + rb) * 32, B, P, lrow, lcol, blk[rb]);
-        if constexpr (WV) gv_write_d<T, AT, NW, FAST>(sdt, t0, P, K, tid, dreg);
+        if constexpr (WV) gv_write_d<T, AT, NW, FAST>(sdt, t0, P, K, tid, dreg, kn);
     }
     for (int tile = t0; tile < t1; ++tile) {
         const int buf = (tile - t0) & 1;
@@ -1165,11 +1186,11 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
                 const int reg = (KS > 1) ? ks * RPW + rr : rr;
                 const int pix = p0 + tp * 32 + c_row(reg, h);
                 const int atom = ta * 32 + c;
-                dold[rr] = grad_d[(size_t)((FAST || pix < P) ? pix : P - 1) * K + (atom < K ? atom : K - 1)];
+                dold[rr] = grad_d[(size_t)((FAST || pix < P) ? pix : P - 1) * K + k0 + (atom < kn ? atom : kn - 1)];
             }
         }
         if (more) {                                               // next tile's loads fly under this tile's MFMAs
-            if constexpr (WV) gv_load_d<T, AT, NW, FAST>(d, tile + 1, P, K, tid, dreg);
+            if constexpr (WV) gv_load_d<T, AT, NW, FAST>(d, tile + 1, P, K, tid, dreg, k0, kn);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
                 if ((w * RB + rb) * 32 < Bp) gv_load_g<T, FAST>(g, tile + 1, (w * RB + rb) * 32, B, P, lrow, lcol, blk[rb]);
@@ -1237,15 +1258,15 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
                     sum = accd[rr];
                 }
                 const int pix = p0 + tp * 32 + c_row(reg, h);
-                if (atom < K && (FAST || pix < P)) {
-                    float* o = grad_d + (size_t)pix * K + atom;
+                if (atom < kn && (FAST || pix < P)) {
+                    float* o = grad_d + (size_t)pix * K + k0 + atom;
                     if constexpr (ACC) *o = dold[rr] + sum; else *o = sum;   // old value prefetched at the top
                 }
             }
         }
         if (KS == 1) lds_barrier();                             // image reads done before the next tile overwrites
         if constexpr (WV) {
-            if (more) gv_write_d<T, AT, NW, FAST>(sdt + (buf ^ 1) * DBUF, tile + 1, P, K, tid, dreg);
+            if (more) gv_write_d<T, AT, NW, FAST>(sdt + (buf ^ 1) * DBUF, tile + 1, P, K, tid, dreg, kn);
         }
     }
     if constexpr (WV) {
@@ -1253,10 +1274,10 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
     for (int rb = 0; rb < RB; ++rb) {
         const int b0 = (w * RB + rb) * 32;
         if (b0 < Bp) {
-            float* dst = slab + (size_t)blockIdx.x * Bp * K;      // compact rows of K atoms: no padded columns cross HBM
+            float* dst = slab + (size_t)range * Bp * K + k0;      // compact rows of K atoms: no padded columns cross HBM
 #pragma unroll
             for (int at = 0; at < AT; ++at)
-                if (at * 32 + c < K) {
+                if (at * 32 + c < kn) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) dst[(size_t)(b0 + c_row(r, h)) * K + at * 32 + c] = accv[rb][at][r];
                 }
@@ -1440,7 +1461,17 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_f32_kernel(const float* __
 template <int AT, int NW>
 __global__ __launch_bounds__(NW * 64) void grad_v_f32_kernel(const float* __restrict__ g, const float* __restrict__ d,
                                                              float* __restrict__ slab, int B, int Bp, int P, int K, int ntiles,
-                                                             int tiles_per_wg) {
+                                                             int tiles_per_wg, int k_split, int nranges) {
+    // k_split > 0: two workgroups per tile range split the atoms, as in grad_fused_mfma_kernel (K > 64 on the AT = 2 shape:
+    // 512 rows per launch, D read once, one slab per range with both halves' columns; the halves sit on one XCD)
+    int range = blockIdx.x, k0 = 0, kn = K;
+    if (k_split > 0) {
+        const int bid = blockIdx.x, half = (bid >> 3) & 1;
+        range = (bid >> 4) * 8 + (bid & 7);
+        if (range >= nranges) return;                             // whole workgroup, before any barrier
+        k0 = half ? k_split : 0;
+        kn = half ? K - k_split : k_split;
+    }
     using M = Mma<float>;
     using Frag = M::Frag;
     constexpr int TW = 32, KA = AT * 32, NT = NW * 64;
@@ -1452,7 +1483,7 @@ __global__ __launch_bounds__(NW * 64) void grad_v_f32_kernel(const float* __rest
     bf16_t* sdt = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* simg = sdt + 2 * DBUF;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
-    const int t0 = blockIdx.x * tiles_per_wg;
+    const int t0 = range * tiles_per_wg;
     const int t1 = min(ntiles, t0 + tiles_per_wg);
     const int b0 = w * 32;
     const bool active = b0 < Bp;                                 // waves beyond the batch only help staging D
@@ -1469,7 +1500,7 @@ __global__ __launch_bounds__(NW * 64) void grad_v_f32_kernel(const float* __rest
         for (int e = 0; e < DPT; ++e) {
             const int i = tid + e * NT;
             const int px = i / KA, a = i - px * KA;
-            st.dreg[e] = d[(size_t)(tile * TW + (px < TW ? px : TW - 1)) * K + (a < K ? a : K - 1)];
+            st.dreg[e] = d[(size_t)(tile * TW + (px < TW ? px : TW - 1)) * K + k0 + (a < kn ? a : kn - 1)];
         }
         if (active) {
 #pragma unroll
@@ -1484,7 +1515,7 @@ __global__ __launch_bounds__(NW * 64) void grad_v_f32_kernel(const float* __rest
         for (int e = 0; e < DPT; ++e) {
             const int i = tid + e * NT;
             const int px = i / KA, a = i - px * KA;
-            if (px < TW) DImg<float>::put(dst, a * GD + px, DPL, st.dreg[e] * ((a < K) ? 1.0f : 0.0f));
+            if (px < TW) DImg<float>::put(dst, a * GD + px, DPL, st.dreg[e] * ((a < kn) ? 1.0f : 0.0f));
         }
     };
     Stage sa, sb;
@@ -1520,10 +1551,10 @@ __global__ __launch_bounds__(NW * 64) void grad_v_f32_kernel(const float* __rest
         if (tile + 1 < t1) tile_step(tile + 1, 1, sb, sa);
     }
     if (active) {
-        float* dst = slab + (size_t)blockIdx.x * Bp * K;
+        float* dst = slab + (size_t)range * Bp * K + k0;
 #pragma unroll
         for (int at = 0; at < AT; ++at)
-            if (at * 32 + c < K) {
+            if (at * 32 + c < kn) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dst[(size_t)(b0 + c_row(r, h)) * K + at * 32 + c] = accv[at][r];
             }
@@ -1921,12 +1952,12 @@ static int set_lds(const void* fn, size_t bytes) {
 
 template <int AT, int NW>
 static int launch_grad_v_f32_nw(const float* g, const float* d, float* slab, int rows, int rows_p, int P, int K, int nt, int tpw,
-                                int nwg, hipStream_t st) {
+                                int nwg, hipStream_t st, int k_split = 0, int nranges = 0) {
     constexpr int TW = 32;
     const size_t lds = (2 * 3 * (size_t)AT * 32 * (TW + DPAD) + 3 * (size_t)NW * 32 * (TW + DPAD)) * sizeof(bf16_t);
     int rc = set_lds((const void*)grad_v_f32_kernel<AT, NW>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((grad_v_f32_kernel<AT, NW>), dim3(nwg), dim3(NW * 64), lds, st, g, d, slab, rows, rows_p, P, K, nt, tpw);
+    hipLaunchKernelGGL((grad_v_f32_kernel<AT, NW>), dim3(nwg), dim3(NW * 64), lds, st, g, d, slab, rows, rows_p, P, K, nt, tpw, k_split, nranges);
     ADIL_CHECK_LAUNCH();
     return 0;
 }
@@ -2186,6 +2217,24 @@ static int launch_grad_v(const T* g, const float* d, float* grad_vb, int B, int 
     const int nwg_slow = nslow > 0 ? (nslow + tpw_slow - 1) / tpw_slow : 0;
     if constexpr (sizeof(T) == 4) {
         if (vec && P % 32 == 0) {             // fp32 streams: planes split once; 512 rows per launch (K > 64: 256, the D planes double)
+            if constexpr (AT == 4) {
+                // K > 64 (round 4): the AT = 2 shape, 512 rows per launch, the atoms split over workgroup pairs — D read
+                // once, ONE slab per range, so a 512-row batch needs neither a second launch nor a reduce launch
+                const int kh = (K + 1) / 2, half_cu = num_cu() / 2 > 0 ? num_cu() / 2 : 1;
+                const int nt = P / 32, tpw = (nt + half_cu - 1) / half_cu, nr = (nt + tpw - 1) / tpw, grid = 16 * ((nr + 7) / 8);
+                for (int r0 = 0; r0 < Bp; r0 += 512) {
+                    const int rows_p = imin(Bp - r0, 512), rows = imin(B - r0, rows_p);
+                    const float* gc = (const float*)g + (size_t)r0 * P;
+                    int rc;
+                    if (rows_p > 256) rc = launch_grad_v_f32_nw<2, 16>(gc, d, slab, rows, rows_p, P, K, nt, tpw, grid, st, kh, nr);
+                    else if (rows_p > 128) rc = launch_grad_v_f32_nw<2, 8>(gc, d, slab, rows, rows_p, P, K, nt, tpw, grid, st, kh, nr);
+                    else rc = launch_grad_v_f32_nw<2, 4>(gc, d, slab, rows, rows_p, P, K, nt, tpw, grid, st, kh, nr);
+                    if (rc) return rc;
+                    rc = finish_slabs(slab, nr, rows, rows_p, K, grad_vb + (size_t)r0 * K, Bp <= 512, o, st);
+                    if (rc) return rc;
+                }
+                return 0;
+            }
             constexpr int kRows = AT <= 2 ? 512 : 256;
             const int nt = P / 32, tpw = (nt + num_cu() - 1) / num_cu(), nwg = (nt + tpw - 1) / tpw;
             for (int r0 = 0; r0 < Bp; r0 += kRows) {
@@ -2239,7 +2288,7 @@ static size_t grad_fused_lds_bytes() {
 template <typename T, int AT, int NW, int RB, bool FAST>
 static int launch_grad_fused_nw(const T* g, const float* d, const typename Mma<T>::Elem* vpt, int vstride, float* grad_d,
                                 float* slab, int rows, int rows_p, int P, int K, int acc_d, int tile_begin, int tile_end,
-                                int nwg, int tiles_per_wg, hipStream_t st) {
+                                int nwg, int tiles_per_wg, hipStream_t st, int k_split = 0, int nranges = 0) {
     if constexpr (NW % (2 * AT) != 0) {
         return ADIL_EINVAL;
     } else {
@@ -2248,12 +2297,12 @@ static int launch_grad_fused_nw(const T* g, const float* d, const typename Mma<T
             int rc = set_lds((const void*)grad_fused_mfma_kernel<T, AT, NW, RB, FAST, true>, lds);
             if (rc) return rc;
             hipLaunchKernelGGL((grad_fused_mfma_kernel<T, AT, NW, RB, FAST, true>), dim3(nwg), dim3(NW * 64), lds, st, g, d,
-                               vpt, vstride, grad_d, slab, rows, rows_p, P, K, tile_begin, tile_end, tiles_per_wg);
+                               vpt, vstride, grad_d, slab, rows, rows_p, P, K, tile_begin, tile_end, tiles_per_wg, k_split, nranges);
         } else {
             int rc = set_lds((const void*)grad_fused_mfma_kernel<T, AT, NW, RB, FAST, false>, lds);
             if (rc) return rc;
             hipLaunchKernelGGL((grad_fused_mfma_kernel<T, AT, NW, RB, FAST, false>), dim3(nwg), dim3(NW * 64), lds, st, g, d,
-                               vpt, vstride, grad_d, slab, rows, rows_p, P, K, tile_begin, tile_end, tiles_per_wg);
+                               vpt, vstride, grad_d, slab, rows, rows_p, P, K, tile_begin, tile_end, tiles_per_wg, k_split, nranges);
         }
         ADIL_CHECK_LAUNCH();
         return 0;
@@ -2336,6 +2385,51 @@ static int launch_grad_fused(const T* g, const float* d, const float* vp, float*
     return 0;
 }
 
+// ---- fused single pass for 64 < K <= 128 on bf16 streams: two workgroups per tile range split the ATOMS ---------------- //
+// (see grad_fused_mfma_kernel, k_split).  The K <= 64 instantiations (AT = 2 tiles, 8 waves x 2 row blocks = 512 rows) do
+// the work; each half owns ceil(K/2) / floor(K/2) atoms.  One launch per 512-row chunk; later chunks accumulate into grad_d.
+template <typename T>
+static int launch_grad_fused_split(const T* g, const float* d, const float* vp, float* grad_d, float* grad_vb, int B, int P,
+                                   int K, int accumulate_d, void* ws, float* slab, const GradOpts& o, hipStream_t st) {
+    using E = typename Mma<T>::Elem;
+    constexpr int AT = 2;
+    const int Kp = round_up(K, 16), Bp = round_up(B, 32), KA = grad_at(K) * 32;
+    const E* vpt;
+    {
+        int rc = transposed_codes<E>(vp, o, ws, Bp, Kp, KA, st, &vpt);
+        if (rc) return rc;
+    }
+    const int kh = (K + 1) / 2;                                   // atoms of the first half; both halves <= 64
+    const int ntiles = (P + GV_TW - 1) / GV_TW;
+    const bool vec = (P % 8 == 0) && ((uintptr_t)g % 16 == 0);
+    const int nfast = vec ? P / GV_TW : 0, nslow = ntiles - nfast;
+    const int half_cu = num_cu() / 2 > 0 ? num_cu() / 2 : 1;     // two workgroups per range, one workgroup per CU
+    const int tpw_fast = nfast > 0 ? (nfast + half_cu - 1) / half_cu : 1, nr_fast = nfast > 0 ? (nfast + tpw_fast - 1) / tpw_fast : 0;
+    const int tpw_slow = nslow > 0 ? (nslow + half_cu - 1) / half_cu : 1, nr_slow = nslow > 0 ? (nslow + tpw_slow - 1) / tpw_slow : 0;
+    for (int r0 = 0; r0 < Bp; r0 += 512) {
+        const int rows_p = imin(Bp - r0, 512), rows = imin(B - r0, rows_p);
+        const T* gc = g + (size_t)r0 * P;
+        const int acc_d = accumulate_d || (r0 > 0);
+        int rc = 0;
+        if (nr_fast > 0) {
+            const int grid = 16 * ((nr_fast + 7) / 8);
+            if (rows_p > 256) rc = launch_grad_fused_nw<T, AT, 8, 2, true>(gc, d, vpt + r0, Bp, grad_d, slab, rows, rows_p, P, K, acc_d, 0, nfast, grid, tpw_fast, st, kh, nr_fast);
+            else rc = launch_grad_fused_nw<T, AT, 8, 1, true>(gc, d, vpt + r0, Bp, grad_d, slab, rows, rows_p, P, K, acc_d, 0, nfast, grid, tpw_fast, st, kh, nr_fast);
+            if (rc) return rc;
+        }
+        if (nr_slow > 0) {
+            const int grid = 16 * ((nr_slow + 7) / 8);
+            float* sl = slab + (size_t)nr_fast * rows_p * K;
+            if (rows_p > 256) rc = launch_grad_fused_nw<T, AT, 8, 2, false>(gc, d, vpt + r0, Bp, grad_d, sl, rows, rows_p, P, K, acc_d, nfast, ntiles, grid, tpw_slow, st, kh, nr_slow);
+            else rc = launch_grad_fused_nw<T, AT, 8, 1, false>(gc, d, vpt + r0, Bp, grad_d, sl, rows, rows_p, P, K, acc_d, nfast, ntiles, grid, tpw_slow, st, kh, nr_slow);
+            if (rc) return rc;
+        }
+        rc = finish_slabs(slab, nr_fast + nr_slow, rows, rows_p, K, grad_vb + (size_t)r0 * K, Bp <= 512, o, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // ---- grad_d alone through LDS (K > 64, bf16 streams): the grad_d half of the fused kernel, 512 rows per launch -------- //
 template <typename T, int AT, int NW, int RB, bool FAST>
 static int launch_grad_d_lds_nw(const T* g, const typename Mma<T>::Elem* vpt, int vstride, float* grad_d, int rows, int rows_p,
@@ -2347,12 +2441,12 @@ static int launch_grad_d_lds_nw(const T* g, const typename Mma<T>::Elem* vpt, in
         int rc = set_lds((const void*)grad_fused_mfma_kernel<T, AT, NW, RB, FAST, true, false>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((grad_fused_mfma_kernel<T, AT, NW, RB, FAST, true, false>), dim3(nwg), dim3(NW * 64), lds, st, g,
-                           (const float*)nullptr, vpt, vstride, grad_d, (float*)nullptr, rows, rows_p, P, K, tile_begin, tile_end, tpw);
+                           (const float*)nullptr, vpt, vstride, grad_d, (float*)nullptr, rows, rows_p, P, K, tile_begin, tile_end, tpw, 0, 0);
     } else {
         int rc = set_lds((const void*)grad_fused_mfma_kernel<T, AT, NW, RB, FAST, false, false>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((grad_fused_mfma_kernel<T, AT, NW, RB, FAST, false, false>), dim3(nwg), dim3(NW * 64), lds, st, g,
-                           (const float*)nullptr, vpt, vstride, grad_d, (float*)nullptr, rows, rows_p, P, K, tile_begin, tile_end, tpw);
+                           (const float*)nullptr, vpt, vstride, grad_d, (float*)nullptr, rows, rows_p, P, K, tile_begin, tile_end, tpw, 0, 0);
     }
     ADIL_CHECK_LAUNCH();
     return 0;
@@ -2440,6 +2534,14 @@ static int launch_grad_cfg(const T* g, const float* d, const float* vp, float* g
         constexpr int kRows = FusedCfg<T, AT>::kMaxRows;
         // K > 64: a fused launch holds 256 rows only (its grad_v accumulators), so beyond one chunk the two single-output
         // kernels win once grad_d goes through LDS in 512-row launches (launch_grad_d_lds)
+        if constexpr (AT == 4 && sizeof(T) == 2) {
+            // 64 < K <= 128 on bf16 streams (round 4): the atoms split over workgroup pairs, g read once from HBM, D / grad_d /
+            // slabs moved once (launch_grad_fused_split) — up to four 512-row chunks, like the K <= 64 rule below.
+            // ADIL_GRAD_ATOM_SPLIT=0 keeps the round-3 route (grad_d through LDS + the grad_v kernel) for A/B measurements.
+            static const bool split_on = []() { const char* e = getenv("ADIL_GRAD_ATOM_SPLIT"); return !(e && e[0] == '0'); }();
+            if (grad_d != nullptr && grad_vb != nullptr && split_on && Bp <= 4 * 512)
+                return launch_grad_fused_split<T>(g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, slab, o, st);
+        }
         const bool fused = (AT == 4 && sizeof(T) == 2) ? Bp <= kRows : Bp <= 4 * kRows;
         if (grad_d != nullptr && grad_vb != nullptr && fused)
             return launch_grad_fused<T, AT>(g, d, vp, grad_d, grad_vb, B, P, K, accumulate_d, ws, slab, o, st);

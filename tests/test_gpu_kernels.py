@@ -200,7 +200,7 @@ def test_linearity_full_size():
 
 
 @pytest.mark.parametrize("b,k,dt", [(544, 50, torch.bfloat16), (192, 100, torch.bfloat16), (96, 128, torch.float32),
-                                    (130, 10, torch.bfloat16)])
+                                    (130, 10, torch.bfloat16), (512, 100, torch.bfloat16), (300, 100, torch.float32)])
 def test_full_size_configs(b, k, dt):
     """BASELINE image size (P = 150528) at the atom counts of the other configs (K = 10 / 50 / 100 / 128), ragged
     batch sizes, against fp64 matmuls on the device (operands rounded as the kernels round them)."""

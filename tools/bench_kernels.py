@@ -74,3 +74,23 @@ gvp = ops.pack_codes(torch.randn(B, K, generator=g0).to(dev) * 0.01, None, B)
 t = timeit(lambda: ops.zstep_(z, mz, sz, dpt, gvp, B, hz, -8 / 255, 8 / 255), n=10)
 print(f"z-step (fp32) {t*1e3:9.1f} us  {(6 * B * P * 4 + P * K * 4)/t/1e6:8.1f} GB/s algorithmic")
 t = timeit(lambda: engine.PseudoInverse(d), n=5); print(f"Gram + inverse + D_dagger (once per attack call) {t*1e3:9.1f} us")
+
+# ---- round 4: the z-step that also leaves the next iteration's codes (adil_zstep_codes): no contraction launch for z D_dagger^T
+nbytes = ops.zstep_codes_slab_bytes(B, P, K)
+if nbytes:
+    slabs = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    state = {"v": None}
+    def iteration_fused():
+        vpk = ops.pack_codes(state["v"], None, B) if state["v"] is not None else torch.zeros_like(gvp)
+        xt = ops.synth(x32, d, vpk, B)
+        _, gv = ops.grad(g32, d, None, B, want_d=False, defer_v=True)
+        state["v"] = ops.zstep_codes_(z, mz, sz, dpt, ops.pack_codes(gv, None, B), B, hz, -8 / 255, 8 / 255, slabs)
+    t = timeit(iteration_fused, n=10)
+    alg = 8 * B * P * 4 + 3 * P * K * 4
+    print(f"DDrague iteration, codes from the z-step (fp32, dictionary path) {t*1e3:9.1f} us  {alg/t/1e6:8.1f} GB/s algorithmic ({alg/1e9:.2f} GB)")
+    t = timeit(lambda: ops.zstep_codes_(z, mz, sz, dpt, gvp, B, hz, -8 / 255, 8 / 255, slabs), n=10)
+    print(f"z-step + next codes (fp32) {t*1e3:9.1f} us  {(6 * B * P * 4 + P * K * 4)/t/1e6:8.1f} GB/s algorithmic")
+    t = timeit(lambda: ops.pack_codes(state["v"], None, B), n=10)
+    print(f"pack_codes from the z-step's {state['v'].nslabs} slabs {t*1e3:9.1f} us")
+    t = timeit(lambda: ops.grad(z, dpt, None, B, want_d=False, defer_v=True), n=10)
+    print(f"z D_dagger^T as its own launch (what the fusion removes) {t*1e3:9.1f} us  {(B * P * 4 + P * K * 4)/t/1e6:8.1f} GB/s algorithmic")

@@ -26,7 +26,7 @@ PEAK_TFLOPS = 2500.0
 
 def short(name):
     m = re.search(r"(synth_mfma_kernel|grad_fused_mfma_kernel|grad_fused_f32_kernel|grad_v_f32_kernel|grad_d_mfma_kernel|"
-                  r"grad_v_mfma_kernel|zstep_mfma_kernel|gram_mfma_kernel|dict_rightmul_mfma_kernel)<([^>]*)", name)
+                  r"grad_v_mfma_kernel|zstep_mfma_kernel|zstep_codes_kernel|gram_mfma_kernel|dict_rightmul_mfma_kernel)<([^>]*)", name)
     if not m:
         return None
     args = m.group(2).replace("unsigned short", "bf16").replace("(bool)1", "1").replace("(bool)0", "0").replace("true", "1").replace("false", "0")
@@ -75,7 +75,7 @@ def main():
     if len(sys.argv) > 2:
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from dl_attack_on_imagenet_amd.build import source_hash
-        groups = {"synth": "synth_mfma_kernel<bf16", "grad": "grad_fused_mfma_kernel<bf16", "zstep_": "zstep_mfma_kernel",
+        groups = {"synth": "synth_mfma_kernel<bf16", "grad": "grad_fused_mfma_kernel<bf16", "zstep_": "zstep_mfma_kernel", "zstep_codes_": "zstep_codes_kernel",
                   "grad[z D_dagger^T]": "grad_v_f32_kernel"}
         rec = {"_source": {"counters": path, "kernel_source_hash": source_hash(), "atoms": int(os.environ.get("K", 50)),
                            "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)"},

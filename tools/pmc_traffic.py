@@ -35,7 +35,7 @@ def short(name):
     if name.startswith("grad_v_reduce_kernel after "):
         return "grad_v_reduce after " + (short(name[len("grad_v_reduce_kernel after "):]) or "?")
     m = re.search(r"(synth_mfma_kernel|grad_fused_mfma_kernel|grad_fused_f32_kernel|grad_v_f32_kernel|grad_d_mfma_kernel|grad_v_mfma_kernel|grad_v_reduce_kernel|adamw_clamp_kernel|"
-                  r"adamw_l1ball_kernel|pack_codes_kernel|transpose_codes_kernel|zstep_mfma_kernel|gather_images_kernel)<([^>]*)", name)
+                  r"adamw_l1ball_kernel|pack_codes_kernel|transpose_codes_kernel|zstep_mfma_kernel|zstep_codes_kernel|gather_images_kernel)<([^>]*)", name)
     if m:
         return f"{m.group(1)}<{m.group(2).split('>')[0]}>"
     if "direct_copy_kernel" in name or "copy" in name.lower():
@@ -63,6 +63,7 @@ def main():
               "adamw_clamp_": [k for k in rows if k.startswith("adamw_clamp")],
               "adamw_l1ball_": [k for k in rows if k.startswith("adamw_l1ball")],
               "zstep_": [k for k in rows if k.startswith("zstep_mfma")],
+              "zstep_codes_": [k for k in rows if k.startswith("zstep_codes")],
               "grad[z D_dagger^T]": [k for k in rows if k.startswith(("grad_v_mfma_kernel<float", "grad_v_f32_kernel"))],
               "pack_codes": [k for k in rows if k.startswith("pack_codes")]}
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -75,7 +76,7 @@ def main():
     for g, ks in groups.items():
         # bf16 instantiations only (the bench workload): template arg 't' = unsigned short
         sel = [k for k in ks if "<unsigned short" in k or "<" not in k or
-               g in ("adamw_clamp_", "adamw_l1ball_", "pack_codes", "zstep_", "grad[z D_dagger^T]")]
+               g in ("adamw_clamp_", "adamw_l1ball_", "pack_codes", "zstep_", "zstep_codes_", "grad[z D_dagger^T]")]
         if sel:
             result[g] = sum(rows[k]["hbm_bytes"] for k in sel)
     json.dump(result, open(out, "w"), indent=1)
