@@ -1091,13 +1091,20 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
     // grad_d and of the range's slab: D, grad_d and the slabs move once.  The halves of a range sit 8 block ids apart,
     // i.e. on the same XCD under the round-robin placement (speed only: the second reader of a g tile then finds it in
     // that XCD's L2 instead of fetching it from HBM again).
-    int range = blockIdx.x, k0 = 0, kn = K;
+    int range = blockIdx.x, k0 = 0, kn = K, flip = 0;
     if (k_split > 0) {
         const int bid = blockIdx.x, half = (bid >> 3) & 1;
         range = (bid >> 4) * 8 + (bid & 7);
         if (range >= nranges) return;                             // whole workgroup, before any barrier
         k0 = half ? k_split : 0;
         kn = half ? K - k_split : k_split;
+        // The two halves of a range walk its tiles in orders that differ by a swap of neighbours (0 1 2 3 ... against
+        // 1 0 3 2 ...): at every step they fetch DIFFERENT tiles of g, and the tile one of them needs next is the one its
+        // partner brought into the XCD's L2 a step earlier.  Walking in the same order, both waited for the same HBM
+        // round trip at every step (the loop is one tile deep: its pace is the load latency) and the pair took as long
+        // as two separate passes over g.  Odd / even ranges start on opposite phases, so that at any moment half of the
+        // pairs are on their HBM step and half on their L2 step.
+        flip = half ^ (range & 1);
     }
     // WV = false: the grad_d half alone (no D tile, no grad_v accumulators, no slab) — the LDS-staged grad_d kernel of
     // K > 64, where the direct-load kernel is left with 128-byte row pieces (finding 17) and the fused kernel with 256 rows.
@@ -1128,6 +1135,8 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int t0 = tile_begin + range * tiles_per_wg;
     const int t1 = min(tile_end, t0 + tiles_per_wg);
+    const int nt = t1 - t0;                                      // tiles of this range, visited in the order tile_at(0), tile_at(1), ...
+    auto tile_at = [&](int i) __attribute__((always_inline)) { const int j = i ^ flip; return t0 + (j < nt ? j : i); };
     const int ti = w % NTILE, ks = w / NTILE, tp = ti & 1, ta = ti >> 1;
 
     f32x16 accv[WV ? RB : 1][WV ? AT : 1];
@@ -1157,16 +1166,18 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
 
     float dreg[DPT];
     u32x4 blk[RB][NLD];
-    if (t0 < t1) {
-        if constexpr (WV) gv_load_d<T, AT, NW, FAST>(d, t0, P, K, tid, dreg, k0, kn);
+    if (nt > 0) {
+        const int tf = tile_at(0);
+        if constexpr (WV) gv_load_d<T, AT, NW, FAST>(d, tf, P, K, tid, dreg, k0, kn);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
-            if ((w * RB + rb) * 32 < Bp) gv_load_g<T, FAST>(g, t0, (w * RB + rb) * 32, B, P, lrow, lcol, blk[rb]);
-        if constexpr (WV) gv_write_d<T, AT, NW, FAST>(sdt, t0, P, K, tid, dreg, kn);
+            if ((w * RB + rb) * 32 < Bp) gv_load_g<T, FAST>(g, tf, (w * RB + rb) * 32, B, P, lrow, lcol, blk[rb]);
+        if constexpr (WV) gv_write_d<T, AT, NW, FAST>(sdt, tf, P, K, tid, dreg, kn);
     }
-    for (int tile = t0; tile < t1; ++tile) {
-        const int buf = (tile - t0) & 1;
-        const bool more = tile + 1 < t1;
+    for (int ti_ = 0; ti_ < nt; ++ti_) {
+        const int tile = tile_at(ti_), tnext = tile_at(ti_ + 1);
+        const int buf = ti_ & 1;
+        const bool more = ti_ + 1 < nt;
         const int p0 = tile * GV_TW;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
@@ -1190,10 +1201,10 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
             }
         }
         if (more) {                                               // next tile's loads fly under this tile's MFMAs
-            if constexpr (WV) gv_load_d<T, AT, NW, FAST>(d, tile + 1, P, K, tid, dreg, k0, kn);
+            if constexpr (WV) gv_load_d<T, AT, NW, FAST>(d, tnext, P, K, tid, dreg, k0, kn);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
-                if ((w * RB + rb) * 32 < Bp) gv_load_g<T, FAST>(g, tile + 1, (w * RB + rb) * 32, B, P, lrow, lcol, blk[rb]);
+                if ((w * RB + rb) * 32 < Bp) gv_load_g<T, FAST>(g, tnext, (w * RB + rb) * 32, B, P, lrow, lcol, blk[rb]);
         }
         lds_barrier();                                          // all images + D[buf] visible
         if constexpr (WV) {                                       // ---- grad_v: rows of this wave, all 64 pixels
@@ -1266,7 +1277,7 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
         }
         if (KS == 1) lds_barrier();                             // image reads done before the next tile overwrites
         if constexpr (WV) {
-            if (more) gv_write_d<T, AT, NW, FAST>(sdt + (buf ^ 1) * DBUF, tile + 1, P, K, tid, dreg, kn);
+            if (more) gv_write_d<T, AT, NW, FAST>(sdt + (buf ^ 1) * DBUF, tnext, P, K, tid, dreg, kn);
         }
     }
     if constexpr (WV) {

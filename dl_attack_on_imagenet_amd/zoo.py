@@ -754,14 +754,39 @@ class _FusedStem(_Fp32Tables):
         return ops.resnet_stem(x, self.w_fwd, self.w_bwd, self.scale, self.shift, self.mean, self.inv_std)
 
 
+class _Fp32Head(nn.Module):
+    """Global average pool + the last linear layer in fp32, whatever dtype the network is cast to: the weights keep their
+    fp32 bits (like _Fp32Tables), the pooled features are widened before the layer, the logits come out fp32.
+    Why (round 4, VERDICT r3 #1c): a bf16 head rounds logits of magnitude 16-64 to steps of 0.125-0.25, which is the scale
+    on which the attack's argmax decisions ("fooled") and its margin loss are taken; the head is 2 MFLOP per image next to
+    the backbone's 4 GFLOP, so keeping it fp32 costs nothing measurable.  The backbone stays bf16."""
+
+    def __init__(self, fc: nn.Linear):
+        super().__init__()
+        self.register_buffer('weight', fc.weight.detach().float().clone())
+        self.register_buffer('bias', fc.bias.detach().float().clone() if fc.bias is not None else torch.zeros(fc.out_features))
+
+    def _apply(self, fn, recurse=True):
+        keep = {n: getattr(self, n) for n in ('weight', 'bias')}
+        super()._apply(fn, recurse)
+        for n, t in keep.items():
+            setattr(self, n, t.to(device=fn(t).device))
+        return self
+
+    def forward(self, x):
+        return F.linear(x.float().mean(dim=(2, 3)), self.weight, self.bias)
+
+
 class FusedResNet(nn.Module):
     """A frozen ResNet whose BatchNorm(eval) / residual add / ReLU run as ONE elementwise kernel per convolution
     (`ops.affine_act`, forward and input-gradient backward) instead of 2-3 separate PyTorch kernels.  Convolution
     weights are untouched; the function is the original network's (up to one rounding per activation).  GPU only.
-    With `normalize=(mean, std)` the input normalisation and the whole first stage run in the stem kernels."""
+    With `normalize=(mean, std)` the input normalisation and the whole first stage run in the stem kernels.
+    `head_fp32`: global pooling + the last linear layer in fp32 with fp32 logits (_Fp32Head)."""
 
-    def __init__(self, net: ResNet, normalize=None):
+    def __init__(self, net: ResNet, normalize=None, head_fp32: bool = False):
         super().__init__()
+        self.head32 = _Fp32Head(net.fc) if head_fp32 else None
         if normalize is not None:
             self.fstem = _FusedStem(net.conv1, net.bn1, *normalize)
             self.stem, self.maxpool = None, None
@@ -781,6 +806,8 @@ class FusedResNet(nn.Module):
         x = self.layers(x)
         if isinstance(x, tuple):
             x = x[0]
+        if self.head32 is not None:
+            return self.head32(x)
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 
@@ -827,11 +854,14 @@ def fit_centroid_head(model: nn.Module, images: torch.Tensor, labels: torch.Tens
 def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights: Optional[str] = None,
                      device=None, dtype: torch.dtype = torch.float32, channels_last: bool = False,
                      fold_bn: bool = False, pad_input_channels: int = 0, fuse_bn_act: bool = False,
-                     fuse_stem: bool = False) -> nn.Module:
+                     fuse_stem: bool = False, head_fp32: bool = False) -> nn.Module:
     """Sequential(Normalize, net), eval mode, parameters frozen — the object both CLIs hand to ADIL.
     fold_bn / pad_input_channels / fuse_bn_act / fuse_stem apply the function-preserving rewrites above (off by
     default); fuse_bn_act (ResNets, GPU only) supersedes fold_bn; fuse_stem (with fuse_bn_act, bf16 only) moves the
-    normalisation and the first stage into the stem kernels (the Sequential then holds the network alone)."""
+    normalisation and the first stage into the stem kernels (the Sequential then holds the network alone); head_fp32
+    (with fuse_bn_act) keeps global pooling + the last linear layer in fp32 under a bf16 cast (fp32 logits)."""
+    if head_fp32 and not fuse_bn_act:
+        raise ValueError("head_fp32 is a switch of the FusedResNet path (fuse_bn_act=True)")
     key = canonical_name(name)
     with torch.random.fork_rng(devices=[]):
         torch.manual_seed(seed)
@@ -846,7 +876,7 @@ def build_classifier(name: str, num_classes: int = 1000, seed: int = 0, weights:
         stem_fused = bool(fuse_stem)
         if stem_fused and dtype != torch.bfloat16:
             raise ValueError("fuse_stem needs a bfloat16 network (the stem kernels produce bf16 activations)")
-        net = FusedResNet(net, normalize=(mean, std) if stem_fused else None)
+        net = FusedResNet(net, normalize=(mean, std) if stem_fused else None, head_fp32=head_fp32)
     elif fold_bn:
         fold_batchnorm_(net)
     model = nn.Sequential(net) if stem_fused else nn.Sequential(Normalize(mean=mean, std=std), net)
