@@ -472,7 +472,8 @@ def spawn_ranks(args):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)         # HSA_ENABLE_IPC_MODE_LEGACY is set by dist.init_from_env inside every rank, whoever launched it
+    env = dict(os.environ)         # HSA_ENABLE_IPC_MODE_LEGACY: also set by dist.init_from_env inside every rank, whoever launched it
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
     return subprocess.run(cmd, env=env).returncode
 

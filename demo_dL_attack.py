@@ -74,7 +74,9 @@ def spawn_ranks(args):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={max(1, n)}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=dict(os.environ)).returncode      # HSA_ENABLE_IPC_MODE_LEGACY: dist.init_from_env, in every rank
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # in place before a rank's first HIP call, whatever the rank's script does first
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main(args):

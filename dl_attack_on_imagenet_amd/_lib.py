@@ -23,6 +23,11 @@ SIGNATURES = {
     "adil_synth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "adil_synth_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                c_void_p]),
+    "adil_dict_to_fp8": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "adil_adamw_clamp_fp8": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,
+                                     c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "adil_synth_fp8_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
+                                      c_int, c_void_p]),
     "adil_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                           c_void_p, c_size_t, c_void_p, c_void_p]),
     "adil_adamw_clamp": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,

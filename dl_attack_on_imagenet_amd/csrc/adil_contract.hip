@@ -628,7 +628,39 @@ __device__ __forceinline__ void fill_dict_slice(const float* __restrict__ d, typ
     }
 }
 
-template <typename T, typename O, bool XACC, bool FAST, int HOIST = 4, int NWV = 4>
+// The 128-pixel slice of a dictionary that is ALREADY fp8 (the persistent e4m3 copy adil_adamw_clamp_fp8 maintains,
+// bytes = e4m3(256 d), P x K row-major): one contiguous run of 128 K bytes, copied dword-wise into the tile-major LDS rows
+// (K % 4 == 0, so a dword never straddles two pixels; row stride Ks is a multiple of 8).  A quarter of the bytes the fp32
+// master costs, and no conversion work.
+template <int NT>
+__device__ __forceinline__ void fill_dict_slice_fp8(const unsigned char* __restrict__ d8, unsigned char* sd, int p0, int K, int Kp,
+                                                    int Ks, int tid) {
+    const unsigned* src = reinterpret_cast<const unsigned*>(d8 + (size_t)p0 * K);
+    const int nq = 32 * K;                                        // dwords of the slice
+    const float rk = 1.0f / (float)K;
+    for (int q0 = tid; q0 < nq; q0 += NT * 8) {
+        unsigned val[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = q0 + NT * u;
+            val[u] = src[q < nq ? q : nq - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = q0 + NT * u;
+            if (q < nq) {
+                const int i = 4 * q;
+                const int r = (int)(((float)i + 0.5f) * rk);      // i / K (exact, see fill_dict_slice)
+                const int k = i - r * K;
+                *reinterpret_cast<unsigned*>(sd + ((r & 3) * 32 + (r >> 2)) * Ks + k) = val[u];
+            }
+        }
+    }
+    if (NT == 256 || tid < 256)
+        for (int k = K + (tid & 1); k < Kp; k += 2) sd[(((tid >> 1) & 3) * 32 + (tid >> 3)) * Ks + k] = 0;   // e4m3 0x00 = +0
+}
+
+template <typename T, typename O, bool XACC, bool FAST, int HOIST = 4, int NWV = 4, bool PACKED = false>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV == 4 ? 3 : 2))) void synth_mfma_kernel(const T* __restrict__ x, const float* __restrict__ d,
                                                          const float* __restrict__ vp, T* __restrict__ out, int B,
                                                          int P, int K, int Kp, float delta_clamp, int pixel_clamp,
@@ -642,7 +674,10 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
     // consecutive tiles go to consecutive workgroups, i.e. round-robin over the 8 XCDs: for this pure stream that is
     // 8 % faster than giving each XCD one contiguous range of tiles (measured)
     const int p0 = (tile0 + blockIdx.x) * SYNTH_TILE;
-    fill_dict_slice<O, FAST, NWV * 64>(d, sd, p0, P, K, Kp, Ks, tid, sc.d);
+    if constexpr (PACKED)                                         // `d` is the fp8 copy (bytes), not the fp32 master
+        fill_dict_slice_fp8<NWV * 64>(reinterpret_cast<const unsigned char*>(d), reinterpret_cast<unsigned char*>(sd), p0, K, Kp, Ks, tid);
+    else
+        fill_dict_slice<O, FAST, NWV * 64>(d, sd, p0, P, K, Kp, Ks, tid, sc.d);
     __syncthreads();
     if constexpr (FAST)
         synth_sweep_buf<T, O, XACC, HOIST, NWV>(x, vp, out, sd, B, P, Kp, Ks, p0, delta_clamp, pixel_clamp,
@@ -2106,6 +2141,48 @@ extern "C" int adil_synth_fp8(const void* x, const float* d, const float* vp, vo
     if (dtype == ADIL_BF16)
         return xacc ? launch_synth_x<bf16_t, fp8_t, true>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, sc, st)
                     : launch_synth_x<bf16_t, fp8_t, false>(x, d, vp, out, B, P, K, delta_clamp, pixel_clamp, sc, st);
+    return ADIL_EINVAL;
+}
+
+template <typename T, bool XACC>
+static int launch_synth_fp8_packed(const void* x, const void* d8, const float* vp, void* out, int B, int P, int K,
+                                   float delta_clamp, int pixel_clamp, OpScale sc, hipStream_t st) {
+    const int Kp = round_up(K, 16), ntiles = P / SYNTH_TILE;
+    const size_t lds = (size_t)SYNTH_TILE * (Kp + DPAD);
+    if (Kp > 64) {
+        int rc = set_lds((const void*)synth_mfma_kernel<T, fp8_t, XACC, true, 8, 4, true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((synth_mfma_kernel<T, fp8_t, XACC, true, 8, 4, true>), dim3(ntiles), dim3(256), lds, st, (const T*)x,
+                           (const float*)d8, vp, (T*)out, B, P, K, Kp, delta_clamp, pixel_clamp, 0, sc);
+    } else {
+        int rc = set_lds((const void*)synth_mfma_kernel<T, fp8_t, XACC, true, 4, 4, true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((synth_mfma_kernel<T, fp8_t, XACC, true, 4, 4, true>), dim3(ntiles), dim3(256), lds, st, (const T*)x,
+                           (const float*)d8, vp, (T*)out, B, P, K, Kp, delta_clamp, pixel_clamp, 0, sc);
+    }
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_synth_fp8_packed(const void* x, const void* d_fp8, const float* vp, void* out, int B, int P, int K, int dtype,
+                                     float v_absmax, float delta_clamp, int pixel_clamp, void* stream) {
+    ADIL_ENTER();
+    if (!d_fp8 || !vp || !out || B <= 0 || P <= 0 || K <= 0 || K > ADIL_MAX_ATOMS || !(v_absmax > 0.0f)) return ADIL_EINVAL;
+    // whole 128-pixel slices of 4-byte groups, 16-byte aligned streams: everything else goes through adil_synth_fp8
+    if (P % SYNTH_TILE != 0 || K % 4 != 0 || P > (1 << 23) || (((uintptr_t)out | (uintptr_t)x) % 16) != 0 || ((uintptr_t)d_fp8 % 4) != 0)
+        return ADIL_EINVAL;
+    OpScale sc;
+    sc.v = 384.0f / v_absmax;
+    sc.d = 256.0f;
+    sc.o = 1.0f / (sc.v * sc.d);
+    hipStream_t st = (hipStream_t)stream;
+    const bool xacc = (x != nullptr) && (delta_clamp < 0.0f);
+    if (dtype == ADIL_F32)
+        return xacc ? launch_synth_fp8_packed<float, true>(x, d_fp8, vp, out, B, P, K, delta_clamp, pixel_clamp, sc, st)
+                    : launch_synth_fp8_packed<float, false>(x, d_fp8, vp, out, B, P, K, delta_clamp, pixel_clamp, sc, st);
+    if (dtype == ADIL_BF16)
+        return xacc ? launch_synth_fp8_packed<bf16_t, true>(x, d_fp8, vp, out, B, P, K, delta_clamp, pixel_clamp, sc, st)
+                    : launch_synth_fp8_packed<bf16_t, false>(x, d_fp8, vp, out, B, P, K, delta_clamp, pixel_clamp, sc, st);
     return ADIL_EINVAL;
 }
 

@@ -4,11 +4,29 @@
 #include "adil_common.h"
 
 // ---- K4 / K8: flat AdamW + clamp[lo,hi] (+ max|delta|) --------------------- //
-template <typename GT>
+// four floats -> four fp8 (OCP e4m3) bytes of 256 x, saturating at the e4m3 range: the operand encoding of the fp8
+// synthesis (adil_contract.hip, Mma<fp8_t>::pack4 with dscale = 256) — the two must stay bit-identical
+__device__ __forceinline__ unsigned fp8x4_of_dict(float a, float b, float c, float d) {
+    const float s = 256.0f;
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(a * s, -448.0f), 448.0f), fminf(fmaxf(b * s, -448.0f), 448.0f), w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(c * s, -448.0f), 448.0f), fminf(fmaxf(d * s, -448.0f), 448.0f), w, true);
+    return (unsigned)w;
+}
+
+__global__ __launch_bounds__(256) void dict_to_fp8_kernel(const float* __restrict__ p, size_t n4, unsigned* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(p)[i];
+        out[i] = fp8x4_of_dict(v.x, v.y, v.z, v.w);
+    }
+}
+
+template <typename GT, bool FP8COPY = false>
 __global__ __launch_bounds__(256) void adamw_clamp_kernel(float* __restrict__ p, const GT* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ s, size_t n,
                                                           AdamWHyper h, float lo, float hi, float* max_abs_delta,
-                                                          const float* __restrict__ dyn) {
+                                                          const float* __restrict__ dyn, unsigned* __restrict__ p_fp8 = nullptr) {
     if (dyn != nullptr) { h.step_size = dyn[0]; h.bc2_sqrt = dyn[1]; }   // step-dependent scalars from device memory (graphs)
     const size_t n4 = n / 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -36,6 +54,7 @@ __global__ __launch_bounds__(256) void adamw_clamp_kernel(float* __restrict__ p,
             po[j] = q;
         }
         reinterpret_cast<float4*>(p)[i] = make_float4(po[0], po[1], po[2], po[3]);
+        if constexpr (FP8COPY) p_fp8[i] = fp8x4_of_dict(po[0], po[1], po[2], po[3]);   // the persistent fp8 copy (n % 4 == 0)
         reinterpret_cast<float4*>(m)[i] = make_float4(mo[0], mo[1], mo[2], mo[3]);
         reinterpret_cast<float4*>(s)[i] = make_float4(so[0], so[1], so[2], so[3]);
     }
@@ -557,11 +576,40 @@ extern "C" int adil_adamw_clamp(float* p, const void* g, int g_dtype, float* m, 
     AdamWHyper h{decay, b1, b2, eps, step_size, bc2_sqrt};
     const int grid = stream_grid(n / 4 + 1, 256);
     if (g_dtype == ADIL_F32)
-        hipLaunchKernelGGL(adamw_clamp_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
-                           (const float*)g, m, s, n, h, lo, hi, max_abs_delta, dyn_scalars);
+        hipLaunchKernelGGL((adamw_clamp_kernel<float, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
+                           (const float*)g, m, s, n, h, lo, hi, max_abs_delta, dyn_scalars, (unsigned*)nullptr);
     else if (g_dtype == ADIL_BF16)
-        hipLaunchKernelGGL(adamw_clamp_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
-                           (const bf16_t*)g, m, s, n, h, lo, hi, max_abs_delta, dyn_scalars);
+        hipLaunchKernelGGL((adamw_clamp_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
+                           (const bf16_t*)g, m, s, n, h, lo, hi, max_abs_delta, dyn_scalars, (unsigned*)nullptr);
+    else
+        return ADIL_EINVAL;
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_dict_to_fp8(const float* d, size_t n, void* d_fp8, void* stream) {
+    ADIL_ENTER();
+    if (!d || !d_fp8 || n == 0 || (n & 3) || ((uintptr_t)d & 15) || ((uintptr_t)d_fp8 & 3)) return ADIL_EINVAL;
+    hipLaunchKernelGGL(dict_to_fp8_kernel, dim3(stream_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, d, n / 4,
+                       (unsigned*)d_fp8);
+    ADIL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int adil_adamw_clamp_fp8(float* p, const void* g, int g_dtype, float* m, float* s, size_t n, float decay,
+                                    float b1, float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi,
+                                    float* max_abs_delta, const float* dyn_scalars, void* p_fp8, void* stream) {
+    ADIL_ENTER();
+    if (!p || !g || !m || !s || !p_fp8 || n == 0 || (n & 3)) return ADIL_EINVAL;
+    if ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)s | (uintptr_t)g) & 15) || ((uintptr_t)p_fp8 & 3)) return ADIL_EINVAL;
+    AdamWHyper h{decay, b1, b2, eps, step_size, bc2_sqrt};
+    const int grid = stream_grid(n / 4 + 1, 256);
+    if (g_dtype == ADIL_F32)
+        hipLaunchKernelGGL((adamw_clamp_kernel<float, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, (const float*)g, m, s,
+                           n, h, lo, hi, max_abs_delta, dyn_scalars, (unsigned*)p_fp8);
+    else if (g_dtype == ADIL_BF16)
+        hipLaunchKernelGGL((adamw_clamp_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, (const bf16_t*)g, m,
+                           s, n, h, lo, hi, max_abs_delta, dyn_scalars, (unsigned*)p_fp8);
     else
         return ADIL_EINVAL;
     ADIL_CHECK_LAUNCH();

@@ -47,6 +47,14 @@ def init_from_env(backend: Optional[str] = None, slurm: bool = False) -> Tuple[i
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or os.environ.get("ADIL_FORCE_REDUCER") == "1":
+        if IPC_ENV not in os.environ and torch.cuda.is_initialized():
+            # the ROCr runtime read its environment at this process's first HIP call, which has already
+            # happened (e.g. the classifier was moved to the GPU before ADIL.learn_dictionary_distributed): setting the
+            # variable now cannot take effect any more
+            warnings.warn(f"{IPC_ENV} was not set when this process initialised the GPU; on hosts whose driver only supports "
+                          f"dmabuf IPC, RCCL then fails with `hipIpcGetMemHandle: invalid argument`.  Export {IPC_ENV}=0 "
+                          "in the launcher's environment, or call dist.init_from_env() before the first torch.cuda call.",
+                          RuntimeWarning)
         os.environ.setdefault(IPC_ENV, "0")
     if (world > 1 or os.environ.get("ADIL_FORCE_REDUCER") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -169,7 +177,10 @@ class DictGradReducer:
         self.group = group
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
-        self.timing = bool(timing)               # bench.py: HIP-event bracket around every start -> wait
+        # bench.py: HIP-event bracket around every start -> wait.  ADIL_REDUCER_TIMING=1 switches it on for a learner that
+        # builds its own reducer (ADIL.learn_dictionary_distributed), so that any multi-rank run can say what its
+        # collective cost (tests/dist_learn_worker.py records it)
+        self.timing = bool(timing) or os.environ.get("ADIL_REDUCER_TIMING") == "1"
         self._brackets, self.bytes_per_call = [], 0
         self.saw_async_work = False              # the asynchronous (RCCL) branch of all_reduce_start has been taken
 

@@ -173,10 +173,19 @@ class DictionaryLearner:
         # configs[4]: the D.V contraction of the synthesis on fp8 MFMAs.  Legal here because every row of v lives in
         # the l1 ball of radius eps after update_v (so |v| <= eps bounds the code scale) and |d| <= 1 after update_d.
         self.fp8_absmax = float(eps) if fp8_synth else None
+        # ... and on a PERSISTENT fp8 copy of D (round 4): the AdamW + clamp launch keeps it current (one more byte per
+        # element written), the synthesis reads it instead of the fp32 master (a quarter of the dictionary bytes)
+        self.d_fp8 = ops.dict_to_fp8(self.d) if (fp8_synth and ops.fp8_dict_supported(self.d)) else None
         self._graph = None                       # (graph, x, index, loss, fooled, batch size, labels) once `use_graph` captured a step
         self._graph_warm = 0
         self._dyn_d = self._dyn_v = None
         self._pending = None                     # handle of the step's all-reduce between forward_backward and update_d
+
+    def sync_fp8_copy(self) -> None:
+        """Re-derive the persistent fp8 copy from the fp32 master — after `d` was overwritten from outside (a warm start, a
+        test forcing a state); update_d keeps it current by itself."""
+        if self.d_fp8 is not None:
+            ops.dict_to_fp8(self.d, out=self.d_fp8)
 
     # -- pieces ------------------------------------------------------------- #
     def synthesize(self, x: Tensor, index: Tensor, want_d: bool = True, want_v: bool = True):
@@ -188,7 +197,7 @@ class DictionaryLearner:
         vpt = None
         if want_d:
             vp, vpt = vp
-        xt = ops.synth(_flat_images(x), self.d, vp, b, fp8_absmax=self.fp8_absmax)
+        xt = ops.synth(_flat_images(x), self.d, vp, b, fp8_absmax=self.fp8_absmax, d_fp8=self.d_fp8)
         return xt, (vp, vpt, b)
 
     def backward(self, g: Tensor, codes, want_d: bool = True, want_v: bool = True):
@@ -239,7 +248,7 @@ class DictionaryLearner:
             self._pending.wait()                                 # stream-ordered: the host does not block
             self._pending = None
         h = self._next_scalars(self.sched_d, self._dyn_d)
-        ops.adamw_clamp_(self.d, gd, self.m_d, self.s_d, h, -1.0, 1.0, dyn=self._dyn_d)    # K4: step + update_d
+        ops.adamw_clamp_(self.d, gd, self.m_d, self.s_d, h, -1.0, 1.0, dyn=self._dyn_d, p_fp8=self.d_fp8)    # K4: step + update_d
 
     def update_v(self, gvb: Optional[Tensor]) -> None:
         if self.v.shape[0] == 0:

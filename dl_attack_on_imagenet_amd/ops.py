@@ -60,7 +60,19 @@ def _workspace(device: torch.device, nbytes: int) -> Tensor:
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
+    # every hand-out starts a new "generation" of this scratch: a SlabGrad that still points into it is stale from here
+    # on (the contract used to live in a docstring only)
+    _generations[key] = _generations.get(key, 0) + 1
+    ws._adil_key = key
     return ws
+
+
+_generations = {}
+
+
+def _workspace_generation(ws: Tensor):
+    key = getattr(ws, "_adil_key", None)
+    return (key, _generations.get(key)) if key is not None else None
 
 
 def dict_shape(d: Tensor) -> Tuple[int, int]:
@@ -185,18 +197,28 @@ class SlabGrad:
     adamw_l1ball_ and pack_codes — sum the slabs inside their own launch (same fixed order as the library's reduce
     kernel, identical bits), so no reduction launch sits between producer and consumer.  Valid until the workspace of
     the current stream is used again (the next ops.grad / gram / atom_norms call): consume it right away."""
-    __slots__ = ("ws", "ptr", "nslabs", "rows", "batch", "k")
+    __slots__ = ("ws", "ptr", "nslabs", "rows", "batch", "k", "stamp")
 
     def __init__(self, ws: Tensor, ptr: int, nslabs: int, rows: int, batch: int, k: int):
         self.ws, self.ptr, self.nslabs, self.rows, self.batch, self.k = ws, ptr, nslabs, rows, batch, k
+        # slabs inside the shared per-stream scratch are only valid until that scratch is handed out again: remember its
+        # generation (None for slabs in a buffer the caller owns, e.g. zstep_codes_)
+        self.stamp = _workspace_generation(ws)
 
     @property
     def shape(self):
         return (self.batch, self.k)
 
+    def check_fresh(self) -> None:
+        if self.stamp is not None and _generations.get(self.stamp[0]) != self.stamp[1]:
+            raise RuntimeError("stale SlabGrad: the scratch workspace it points into has been used by another ops.grad / gram / "
+                               "atom_norms call on this stream since it was produced — consume a deferred gradient "
+                               "(adamw_l1ball_ / pack_codes) before the next such call")
+
 
 def _slab_args(src):
     if isinstance(src, SlabGrad):
+        src.check_fresh()
         return c_void_p(src.ptr), src.nslabs, src.rows
     return c_void_p(0), 0, 0
 
@@ -266,12 +288,33 @@ def gather_images(src: Tensor, index: Optional[Tensor], out: Optional[Tensor] = 
     return out
 
 
+def fp8_dict_supported(d: Tensor) -> bool:
+    """Shapes adil_synth_fp8_packed takes: whole 128-pixel slices, atoms in groups of four."""
+    p, k = dict_shape(d)
+    return p % 128 == 0 and k % 4 == 0 and p <= (1 << 23)
+
+
+def dict_to_fp8(d: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """The persistent fp8 copy of a dictionary: bytes e4m3(256 d), same shape, uint8 (adil_dict_to_fp8)."""
+    lib = _lib.load()
+    _dev(d, "d", torch.float32)
+    if out is None:
+        out = torch.empty(d.shape, dtype=torch.uint8, device=d.device)
+    _dev(out, "out", torch.uint8)
+    if out.numel() != d.numel() or d.numel() % 4:
+        raise ValueError("dict_to_fp8: same number of elements, a multiple of 4")
+    _lib.check(lib.adil_dict_to_fp8(_ptr(d), d.numel(), _ptr(out), _stream()), "adil_dict_to_fp8")
+    return out
+
+
 def synth(x: Optional[Tensor], d: Tensor, vp: Tensor, batch: int, *, out: Optional[Tensor] = None,
           out_shape=None, out_dtype=None, delta_clamp: float = -1.0, pixel_clamp: bool = False,
-          fp8_absmax: Optional[float] = None) -> Tensor:
+          fp8_absmax: Optional[float] = None, d_fp8: Optional[Tensor] = None) -> Tensor:
     """out = x + vp D^T with optional +-delta_clamp on the perturbation and [0,1] pixel clamp.
     fp8_absmax: contract with fp8 (e4m3) operands instead (adil_synth_fp8); the value is a bound on |vp| (the l1 radius
-    eps for projected codes) and |d| <= 1 is assumed (the invariant update_d maintains)."""
+    eps for projected codes) and |d| <= 1 is assumed (the invariant update_d maintains).
+    d_fp8 (with fp8_absmax): the persistent fp8 copy of d (dict_to_fp8 / adamw_clamp_(..., p_fp8=)): the kernel then reads
+    that — a quarter of the dictionary bytes — instead of converting the fp32 master; same result bit for bit."""
     lib = _lib.load()
     _dev(d, "d", torch.float32)
     _dev(vp, "vp", torch.float32)
@@ -289,6 +332,14 @@ def synth(x: Optional[Tensor], d: Tensor, vp: Tensor, batch: int, *, out: Option
     if fp8_absmax is not None:
         if not fp8_absmax > 0:
             raise ValueError("fp8_absmax must be a positive bound on |vp|")
+        if d_fp8 is not None:
+            _dev(d_fp8, "d_fp8", torch.uint8)
+            if d_fp8.numel() != d.numel() or not fp8_dict_supported(d):
+                raise ValueError("synth: d_fp8 must be the fp8 copy of d (P a multiple of 128, K a multiple of 4)")
+            _lib.check(lib.adil_synth_fp8_packed(_ptr(x), _ptr(d_fp8), _ptr(vp), _ptr(out), batch, p, k,
+                                                 stream_dtype_code(out.dtype), float(fp8_absmax), float(delta_clamp),
+                                                 int(bool(pixel_clamp)), _stream()), "adil_synth_fp8_packed")
+            return out
         _lib.check(lib.adil_synth_fp8(_ptr(x), _ptr(d), _ptr(vp), _ptr(out), batch, p, k, stream_dtype_code(out.dtype),
                                       float(fp8_absmax), float(delta_clamp), int(bool(pixel_clamp)), _stream()),
                    "adil_synth_fp8")
@@ -344,9 +395,23 @@ def grad(g: Tensor, d: Tensor, vp: Optional[Tensor], batch: int, *, want_d: bool
 
 
 def adamw_clamp_(p: Tensor, g: Tensor, m: Tensor, s: Tensor, h: AdamWScalars, lo: float, hi: float,
-                 max_abs_delta: Optional[Tensor] = None, dyn: Optional[Tensor] = None) -> None:
-    """In-place fused AdamW + clamp[lo,hi] on a flat fp32 parameter (adil.py:186,188 / :554-555)."""
+                 max_abs_delta: Optional[Tensor] = None, dyn: Optional[Tensor] = None, p_fp8: Optional[Tensor] = None) -> None:
+    """In-place fused AdamW + clamp[lo,hi] on a flat fp32 parameter (adil.py:186,188 / :554-555).
+    p_fp8: also refresh the persistent fp8 copy of p (dict_to_fp8) inside the same launch."""
     lib = _lib.load()
+    if p_fp8 is not None:
+        for name, t in (("p", p), ("m", m), ("s", s)):
+            _dev(t, name, torch.float32)
+        _dev(g, "g")
+        _dev(p_fp8, "p_fp8", torch.uint8)
+        if not (p.numel() == g.numel() == m.numel() == s.numel() == p_fp8.numel()) or p.numel() % 4:
+            raise ValueError("adamw_clamp_: size mismatch (with p_fp8 the size must be a multiple of 4)")
+        if max_abs_delta is not None:
+            _dev(max_abs_delta, "max_abs_delta", torch.float32)
+        _lib.check(lib.adil_adamw_clamp_fp8(_ptr(p), _ptr(g), stream_dtype_code(g.dtype), _ptr(m), _ptr(s), p.numel(),
+                                            h.decay, h.b1, h.b2, h.eps, h.step_size, h.bc2_sqrt, float(lo), float(hi),
+                                            _ptr(max_abs_delta), _ptr(dyn), _ptr(p_fp8), _stream()), "adil_adamw_clamp_fp8")
+        return
     for name, t in (("p", p), ("m", m), ("s", s)):
         _dev(t, name, torch.float32)
     _dev(g, "g")

@@ -45,7 +45,8 @@ extern "C" {
  * helper launches of a gradient pass moved into their neighbours — adil_pack_codes can emit the transposed codes that
  * adil_grad needs (`vpt`) and can take its rows from the grad_v partial sums ("slabs") of a preceding adil_grad;
  * adil_grad can leave the reduction of those slabs to its consumer (`nslabs_out`); adil_adamw_l1ball consumes them.
- * 7: adil_zstep_codes — the z-step of a DDrague iteration also produces the next iteration's codes (as slabs). */
+ * 7: adil_zstep_codes — the z-step of a DDrague iteration also produces the next iteration's codes (as slabs); the
+ * persistent fp8 copy of the dictionary (adil_dict_to_fp8, adil_adamw_clamp_fp8, adil_synth_fp8_packed). */
 int adil_abi_version(void);
 
 /* Largest K (atoms) the kernels support. */
@@ -99,6 +100,19 @@ int adil_synth(const void* x, const float* d, const float* vp, void* out, int B,
  * products accumulate in fp32 and are scaled back before the add / clamps.  Same arguments and fusion as adil_synth. */
 int adil_synth_fp8(const void* x, const float* d, const float* vp, void* out, int B, int P, int K, int dtype,
                    float v_absmax, float delta_clamp, int pixel_clamp, void* stream);
+
+/* The fp8 variant with a PERSISTENT fp8 copy of the dictionary (round 4): adil_synth_fp8 converts the fp32 master on the
+ * fly, so it still reads P K 4 bytes of D per launch; here D comes in as the bytes e4m3(256 d) — a quarter of that —
+ * produced once by adil_dict_to_fp8 and kept current by adil_adamw_clamp_fp8 (the AdamW + clamp launch of the learning
+ * step writes them next to the fp32 master, 1 byte per element on top of its 28).  Same results as adil_synth_fp8, bit
+ * for bit (the same encoding of the same values).  P a multiple of 128, K a multiple of 4, 16-byte aligned streams;
+ * ADIL_EINVAL otherwise (use adil_synth_fp8).  n must be a multiple of 4 in the two helpers. */
+int adil_dict_to_fp8(const float* d, size_t n, void* d_fp8, void* stream);
+int adil_adamw_clamp_fp8(float* p, const void* g, int g_dtype, float* m, float* s, size_t n, float decay, float b1,
+                         float b2, float eps, float step_size, float bc2_sqrt, float lo, float hi, float* max_abs_delta,
+                         const float* dyn_scalars, void* p_fp8, void* stream);
+int adil_synth_fp8_packed(const void* x, const void* d_fp8, const float* vp, void* out, int B, int P, int K, int dtype,
+                          float v_absmax, float delta_clamp, int pixel_clamp, void* stream);
 
 /* Adjoint of the synthesis in ONE pass over the upstream gradient g = dLoss/d(x+delta):
  *     grad_d  (P x K)  = g^T vp          if grad_d  != NULL   (accumulated into grad_d when accumulate_d)

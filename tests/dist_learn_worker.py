@@ -29,6 +29,7 @@ net = p["net"].to(dev)
 atk = ADIL(net, data_train=None, model_name="dp2", dict_dir=os.path.join(out_dir, "dicts"), **p["kw"])
 learner = atk.learn_dictionary_distributed(IndexedImages(p["images"]), IndexedImages(p["val"]))
 torch.save(learner.d.cpu(), os.path.join(out_dir, f"d_rank{rank}.pt"))
+torch.cuda.synchronize(dev)                                    # the reducer's event brackets are read below
 info = learner.reducer.describe()
 info.update(rank=rank, device=str(dev), device_name=torch.cuda.get_device_name(dev), visible_gpus=torch.cuda.device_count(),
             async_work=bool(getattr(learner.reducer, "saw_async_work", False)))

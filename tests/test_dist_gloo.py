@@ -31,17 +31,23 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _problem():
+def _problem(n_img=N_IMG, n_val=N_VAL):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     from oracle import adil_oracle as O
     from tinynet import make_tinynet
     g = torch.Generator().manual_seed(0)
-    images = torch.rand(N_IMG, 3, 16, 16, generator=g)
-    val = torch.rand(N_VAL, 3, 16, 16, generator=g)
+    images = torch.rand(n_img, 3, 16, 16, generator=g)
+    val = torch.rand(n_val, 3, 16, 16, generator=g)
     d0 = -1 + 2 * torch.rand(3, 16, 16, K, generator=g)
-    v0raw = torch.rand(N_IMG, K, generator=g)
+    v0raw = torch.rand(n_img, K, generator=g)
     return O, make_tinynet(11), images, val, d0, v0raw
+
+
+# world 8 = the target node: 205 images over 8 ranks (shards of 26 and 25), global batch 100 = 13 / 12 images
+# per rank and step, a last step of 5 images of which most ranks own nothing; 5 validation images: three ranks own no
+# validation image at all and still take part in the sharded validation's collectives
+N_IMG8, N_VAL8, BATCH8, STEPS8 = 205, 5, 100, 2
 
 
 class _Indexed(torch.utils.data.Dataset):
@@ -158,6 +164,72 @@ def _worker(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
+def _worker8(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    O, net, images, val, d0, v0raw = _problem(N_IMG8, N_VAL8)
+    from dl_attack_on_imagenet_amd import dist as adist
+    from dl_attack_on_imagenet_amd.attacks.adil import ADIL
+
+    r, w, _ = adist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    _install_oracle_backend(O)
+    from dl_attack_on_imagenet_amd.attacks import adil as A
+    created = []
+    base = A.ADIL._learner_cls
+
+    class Counting(base):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            created.append(self)
+
+    A.ADIL._learner_cls = Counting
+    atk = ADIL(net, eps=EPS, steps=STEPS8, n_atoms=K, batch_size=BATCH8, data_train=_Indexed(images),
+               data_val=_Indexed(val), model_name="dist_w8", step_size=0.01, is_distributed=True, loss="logits",
+               kappa=50.0, init_d=d0, init_v=v0raw, dict_dir=os.path.join(out_dir, "dicts"), shuffle_seed=5)
+    assert os.path.exists(atk.model_file)
+    lo, hi = adist.shard_bounds(N_IMG8, rank, world)
+    torch.save(dict(collectives=created[0].collectives, rows=created[0].v.shape[0], bounds=(lo, hi), d=created[0].d.clone()),
+               os.path.join(out_dir, f"w8_rank{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_product_distributed_learner_world_8(tmp_path):
+    """The node size the path is built for: 8 ranks (gloo, CPU).  205 images = shards of 26 and 25, the requested global
+    batch of 100 dealt 13 / 12 per rank with the remainder going round, a last step of 5 images (several ranks own
+    nothing and still join the step's all-reduce), validation batches some ranks own nothing of — against the
+    single-process oracle at the same global batches; every rank ends on the same dictionary, bit for bit, after the same
+    number of collectives (one per step)."""
+    world = 8
+    port = _free_port()
+    mp.start_processes(_worker8, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    O, net, images, val, d0, v0raw = _problem(N_IMG8, N_VAL8)
+    from dl_attack_on_imagenet_amd import dist as adist
+    v0 = O.project_onto_l1_ball(v0raw, EPS)
+    batches = [adist.global_epoch_batches(N_IMG8, BATCH8, world, 5, e) for e in range(STEPS8)]
+    vbatches = [adist.global_epoch_batches(N_VAL8, BATCH8, world, 6, e) for e in range(STEPS8)]
+    assert [len(b) for b in batches[0]] == [100, 100, 5] and sorted(i for b in batches[0] for i in b) == list(range(N_IMG8))
+    own = [[len(adist.owned_rows(b, *adist.shard_bounds(N_IMG8, r, world))) for r in range(world)] for b in batches[0]]
+    assert all(sorted(row) == [12] * 4 + [13] * 4 for row in own[:2])          # 100 over 8 ranks: 13 / 12, never 96
+    assert sum(own[2]) == 5 and own[2].count(0) >= 3                            # the ragged last step: ranks that own nothing
+    vown = [[len(adist.owned_rows(b, *adist.shard_bounds(N_VAL8, r, world))) for r in range(world)] for b in vbatches[0]]
+    assert any(0 in row for row in vown)                                        # a validation batch some ranks own nothing of
+    ref = O.learn_dictionary_a(net, images, d0, v0, batches, EPS, 0.01, "logits", False, 50.0, val_images=val,
+                               val_batches=vbatches)
+    d, v, loss_all, fooling_rate_all, val_fool = torch.load(tmp_path / "dicts" / "ImageNet_dist_w8.bin")
+    assert v.shape == (N_IMG8, K)
+    assert float((ref["d"] - d).abs().max()) < 5e-6 and float((ref["v"] - v).abs().max()) < 5e-6   # summation order over 8 partial grad_d
+    assert list(fooling_rate_all) == list(ref["fooling_rate_all"]) and abs(float(val_fool) - ref["val_fool"]) < 1e-6
+    assert max(abs(a - b) for a, b in zip(ref["loss_all"], loss_all)) < 1e-4 * max(1.0, max(map(abs, ref["loss_all"])))
+    recs = [torch.load(tmp_path / f"w8_rank{r}.pt") for r in range(world)]
+    assert sorted(rec["rows"] for rec in recs) == [25] * 3 + [26] * 5
+    assert all(rec["collectives"] == STEPS8 * 3 for rec in recs)                # one all-reduce per step on EVERY rank
+    assert all(torch.equal(rec["d"], recs[0]["d"]) for rec in recs)             # replicated D stays bit-identical
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("world", [2, 4])
 def test_product_distributed_learner_matches_single_process_global_batch(world, tmp_path):
@@ -189,6 +261,58 @@ def test_product_distributed_learner_matches_single_process_global_batch(world, 
     b = torch.load(tmp_path / "dicts" / "ImageNet_dist_savers.bin")
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] and float(a[4]) == float(b[4])
     assert all(torch.load(tmp_path / f"savers_forwards_rank{r}.pt") > 0 for r in range(world))
+
+
+def _stop_worker(rank, world, port, out_dir, deltas):
+    """Rank 0 plays a validation shard that converges early (the slot protocol of adamw_l1ball_kernel restated on the host:
+    skip + stay-stopped when the previous slot is below the threshold, else clear the successor's slot and max the own
+    one), rank 1 owns nothing of the batch (engine._idle_rank_stop_loop); both max-reduce the stop slot every iteration and
+    poll it every STOP_POLL iterations, as engine.solve_codes_adamw does."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from dl_attack_on_imagenet_amd import dist as adist, engine, ops
+    adist.init_from_env(backend="gloo")
+    red = adist.DictGradReducer()
+    calls = {"n": 0}
+    real_max = red.max_
+    red.max_ = lambda t: (calls.__setitem__("n", calls["n"] + 1), real_max(t))[1]
+    dev = torch.device("cpu")
+    max_iter = 100
+    if rank == 1:
+        engine._idle_rank_stop_loop(dev, red, max_iter)
+        iters = None
+    else:
+        stop = ops.StopTest(dev, 1e-6)
+        iters = 0
+        for it in range(max_iter):
+            iters += 1
+            t = stop.t
+            stop.t += 1
+            cur, prev, nxt = t % 3, (t + 2) % 3, (t + 1) % 3
+            if float(stop.slots[prev]) < stop.threshold:
+                stop.slots[cur] = 0.0                              # a skipped launch: stay stopped
+            else:
+                stop.slots[nxt] = 0.0
+                stop.slots[cur] = max(float(stop.slots[cur]), deltas[min(it, len(deltas) - 1)])
+            red.max_(stop.last_slot())
+            if (it + 1) % engine.STOP_POLL == 0 and stop.converged():
+                break
+    torch.save(dict(collectives=calls["n"], iters=iters), os.path.join(out_dir, f"stop_rank{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("deltas,expect", [([1e-2, 1e-3, 1e-5, 5e-7], 4), ([1e-2] * 5 + [1e-7], 8), ([1e-2], 100)])
+def test_idle_rank_pairs_up_with_an_early_converging_shard(deltas, expect, tmp_path):
+    """sharded validation reduces the stop slot once per iteration; a rank that owns nothing of the batch must
+    issue exactly as many of those collectives as the rank that solves it and leave at the same poll point — for a shard
+    that converges at iteration 4 (left at the first poll), at iteration 6 (left at the second), and never (max_iter)."""
+    port = _free_port()
+    mp.start_processes(_stop_worker, args=(2, port, str(tmp_path), deltas), nprocs=2, join=True, start_method="spawn")
+    a, b = torch.load(tmp_path / "stop_rank0.pt"), torch.load(tmp_path / "stop_rank1.pt")
+    assert a["iters"] == expect and a["collectives"] == b["collectives"] == expect
 
 
 def test_global_epoch_batches_equal_steps_and_ownership():

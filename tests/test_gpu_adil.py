@@ -368,7 +368,7 @@ def _two_rank_learner_run(tmp_path, env_extra):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, **env_extra)
+    env = dict(os.environ, ADIL_REDUCER_TIMING="1", **env_extra)
     env.pop("ADIL_FORCE_REDUCER", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(here, "dist_learn_worker.py"), str(tmp_path)],
@@ -391,6 +391,14 @@ def _two_rank_learner_run(tmp_path, env_extra):
     assert dp[1].shape == sp[1].shape and list(dp[3]) == list(sp[3])     # V gathered from both ranks; fooling rates per epoch
     assert max(abs(a - b) for a, b in zip(dp[2], sp[2])) <= 1e-4 * max(1.0, max(abs(a) for a in sp[2]))
     assert abs(float(dp[4]) - float(sp[4])) < 1e-6                        # sharded validation (global stop test)
+    # what the first SCALE line will say about its collective: ONE all-reduce of grad_d (P K fp32) per step,
+    # bracketed start -> wait on the compute stream on every rank
+    from dist_learn_problem import EPOCH_BATCHES, K as K_ATOMS
+    steps = sum(len(e) for e in EPOCH_BATCHES)
+    for i in infos:
+        assert i["bytes_per_allreduce"] == 3 * 32 * 32 * K_ATOMS * 4, i
+        assert i["allreduce_brackets"] == steps and i["allreduce_ms_start_to_wait_mean"] > 0.0, i
+        assert i["allreduce_ms_start_to_wait_max"] >= i["allreduce_ms_start_to_wait_mean"]
     return infos
 
 

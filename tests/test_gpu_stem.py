@@ -113,6 +113,7 @@ def test_fused_stem_resnet_matches_unfused():
     xr, x0, x1 = (x.float().requires_grad_(True), x.clone().requires_grad_(True), x.clone().requires_grad_(True))
     lr, l0, l1 = ref(xr), m0(x0).float(), m1(x1).float()
     e0, e1 = float((l0 - lr).abs().mean()), float((l1 - lr).abs().mean())
+    print("resnet18 logit error vs fp32: plain bf16 %.4f fused %.4f, rms(logits) %.4f" % (e0, e1, float(lr.square().mean().sqrt())))
     assert e1 <= 2.0 * e0 + 1e-3, (e0, e1)                    # factor 2: see the ResNet-50 test below
     (gr,) = torch.autograd.grad(lr.square().sum(), xr)
     (g0,) = torch.autograd.grad(l0.square().sum(), x0)
@@ -205,6 +206,7 @@ def test_fused_resnet50_gradient_matches_fp32():
     xr, x0, x1 = (x.float().requires_grad_(True), x.clone().requires_grad_(True), x.clone().requires_grad_(True))
     lr, l0, l1 = ref(xr), m0(x0).float(), m1(x1).float()
     e0, e1 = float((l0 - lr).abs().mean().detach()), float((l1 - lr).abs().mean().detach())
+    print("resnet50 logit error vs fp32: plain bf16 %.4f fused %.4f, rms(logits) %.4f" % (e0, e1, float(lr.square().mean().sqrt())))
     # both are bf16 networks scored against fp32; which MIOpen algorithms the plain one gets varies with the box, and with it
     # e0 (0.059 on one box, with e1 = 0.0905: a ratio of 1.53 where 1.5 was asserted) — the guard is a factor 2
     assert e1 <= 2.0 * e0 + 1e-3, (e0, e1)
