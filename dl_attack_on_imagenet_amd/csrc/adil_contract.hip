@@ -1622,11 +1622,11 @@ __global__ __launch_bounds__(NW * 64) void grad_v_f32_kernel(const float* __rest
 // MFMA operands of the new contraction: z_new sits in the C layout of the gz tiles (lane = pixel quad, registers = rows)
 // and is needed in the A layout (lane = row, 8 consecutive reduction indices), i.e. transposed: each wave passes it
 // through a private fp32 LDS image of 16 rows x 128 columns — half a block at a time, which is what fits next to the
-// D_dagger planes; the half's rows occupy their own 16 lanes of the A fragment, the other 16 lanes supply zeros (the
-// matrix pipe is idle most of the time in this kernel, LDS space is what is scarce).  Image column j = t*32 + c holds
-// pixel 4c + t — the row order of the LDS slice — so that a k-group of 16 image columns meets 16 consecutive LDS rows of
-// the slice, which come out as the B fragment (lane = atom, 8 consecutive pixels) of a transposing read
-// (ds_read_b64_tr_b16, one per plane and half fragment) — the same planes the gz contraction reads row-wise.
+// D_dagger planes — and contracts each half on the 16-row shape v_mfma_f32_16x16x32_bf16 (a first version put the half
+// into 16 lanes of a 32 x 32 x 16 A operand and zeros into the other 16: twice the matrix work, paid at K = 100).
+// Image column j = t*32 + c holds pixel 4c + t — the row order of the LDS slice — so that a k-group of 32 image columns
+// meets 32 consecutive LDS rows of the slice, which come out as the B fragment (lane = atom, 8 consecutive pixels) of a
+// transposing read (ds_read_b64_tr_b16, two per plane and fragment) — the same planes the gz contraction reads row-wise.
 // z fragments are split into their three bf16 pieces after the read (each element is read exactly once).
 // =========================================================================================================== //
 #define ZC_IS 132                                               // image row stride (floats): 128 + 4, rows shift by 4 banks
@@ -1634,6 +1634,33 @@ __global__ __launch_bounds__(NW * 64) void grad_v_f32_kernel(const float* __rest
 // still fits: 32, 64, 112): with a run-time stride hipcc keeps one address register per (k-group, plane) of the
 // transposing reads — ~50 VGPRs of loop invariants, and the kernel spilled.
 template <int AT> struct ZCodes { static constexpr int KP = AT == 4 ? 112 : AT * 32, KS = KP + DPAD; };
+
+// v_mfma_f32_16x16x32_bf16 operands (layout as in adil_stem.hip, checked on hardware): A lane l -> row l&15, reduction
+// indices 8*(l>>4)+j; B lane l -> column l&15, the same indices; C register r of lane l -> row 4*(l>>4)+r, column l&15.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// B fragment as a transposing read of a [.][GS] bf16 image: lane (li = l&15, gi = l>>4) receives rows rb+8gi .. +7 of
+// column col0 + li (each 16-lane group transposes the 4 x 16 block its lanes address, twice)
+__device__ __forceinline__ bf16x8 colfrag16(const bf16_t* img, int GS, int rb, int col0, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int li = lane & 15, gi = lane >> 4;
+    const bf16_t* a = img + (rb + 8 * gi + (li >> 2)) * GS + col0 + 4 * (li & 3);
+    typedef bf16x4 __attribute__((address_space(3))) * lds_ptr;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)a);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(a + 4 * GS));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#else
+    return bf16x8{};
+#endif
+}
+// the six-piece fp32-grade product of Mma<float>::mma on the 16 x 16 shape (same order: small terms first)
+__device__ __forceinline__ void mma16_split(f32x4v& acc, const Mma<float>::Frag& a, const Mma<float>::Frag& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc, 0, 0, 0);
+}
 
 template <int AT, int RB>
 __global__ __launch_bounds__(512) void zstep_codes_kernel(float* __restrict__ z, float* __restrict__ m,
@@ -1670,13 +1697,16 @@ __global__ __launch_bounds__(512) void zstep_codes_kernel(float* __restrict__ z,
     // accv[0] = the accumulators of the block being processed, accv[1] = the other block's (RB = 2): the block loop stays
     // ROLLED and the two sets trade places after every block — unrolled, the per-block address invariants of the second
     // block were what no longer fitted the register file (reloaded from scratch at every block start).
-    f32x16 accv[RB][AT];
+    constexpr int NT16 = KP / 16;                                // 16-atom tiles of the code contraction
+    f32x4v accv[RB][2][NT16];                                    // [block][half of the block's rows][atom tile]
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int at = 0; at < AT; ++at)
+        for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) accv[rb][at][r] = 0.0f;
+            for (int nt = 0; nt < NT16; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accv[rb][hf][nt][r] = 0.0f;
     float dmax = 0.0f;
 
     for (int s = s0; s < s1; ++s) {
@@ -1744,25 +1774,24 @@ __global__ __launch_bounds__(512) void zstep_codes_kernel(float* __restrict__ z,
                         // rows 16*hf .. 16*hf+15 of the block are complete in the image: v' += z_new D_dagger^T for them.
                         // LDS executes a wave's instructions in order, so these reads see the writes above and the next
                         // half's writes land behind them; the compiler is kept from reordering by the clobbers.
-                        const int hf = grp >> 2;
                         asm volatile("" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
-                        const float keep = ((c >> 4) == hf) ? 1.0f : 0.0f;
-                        const float* ar = img + (c & 15) * ZC_IS + 8 * h;
+                        // the 16 rows as a 16 x 32 A operand per k-group of 32 image columns: lane l -> row l&15,
+                        // columns 32 kg + 8 (l>>4) + j — every lane carries data (no zero half as a 32-row shape would)
+                        const float* ar = img + (lane & 15) * ZC_IS + 8 * (lane >> 4);
 #pragma unroll
-                        for (int kg = 0; kg < SYNTH_TILE / 16; ++kg) {
-                            const float4 q0 = *reinterpret_cast<const float4*>(ar + 16 * kg),
-                                         q1 = *reinterpret_cast<const float4*>(ar + 16 * kg + 4);
-                            const float f[8] = {q0.x * keep, q0.y * keep, q0.z * keep, q0.w * keep,
-                                                q1.x * keep, q1.y * keep, q1.z * keep, q1.w * keep};
+                        for (int kg = 0; kg < SYNTH_TILE / 32; ++kg) {
+                            const float4 q0 = *reinterpret_cast<const float4*>(ar + 32 * kg),
+                                         q1 = *reinterpret_cast<const float4*>(ar + 32 * kg + 4);
+                            const float f[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
                             const Frag za = M::from8(f);
 #pragma unroll
-                            for (int at = 0; at < AT; ++at) {
+                            for (int nt = 0; nt < NT16; ++nt) {
                                 Frag db;
-                                db.h = ColFrag<bf16_t>::load(sd, Ks, 16 * kg, at * 32, lane);
-                                db.m = ColFrag<bf16_t>::load(sd + plane, Ks, 16 * kg, at * 32, lane);
-                                db.l = ColFrag<bf16_t>::load(sd + 2 * plane, Ks, 16 * kg, at * 32, lane);
-                                M::mma(accv[0][at], za, db);
+                                db.h = colfrag16(sd, Ks, 32 * kg, nt * 16, lane);
+                                db.m = colfrag16(sd + plane, Ks, 32 * kg, nt * 16, lane);
+                                db.l = colfrag16(sd + 2 * plane, Ks, 32 * kg, nt * 16, lane);
+                                mma16_split(accv[0][grp >> 2][nt], za, db);
                             }
                             __builtin_amdgcn_sched_barrier(0);   // one k-group at a time: hoisted reads of later ones cost registers
                         }
@@ -1772,13 +1801,15 @@ __global__ __launch_bounds__(512) void zstep_codes_kernel(float* __restrict__ z,
             }
             if constexpr (RB == 2) {                              // the other block's accumulators become the current ones
 #pragma unroll
-                for (int at = 0; at < AT; ++at)
+                for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float t = accv[0][at][r];
-                        accv[0][at][r] = accv[1][at][r];
-                        accv[1][at][r] = t;
-                    }
+                    for (int nt = 0; nt < NT16; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float t = accv[0][hf][nt][r];
+                            accv[0][hf][nt][r] = accv[1][hf][nt][r];
+                            accv[1][hf][nt][r] = t;
+                        }
             }
         }
     }
@@ -1788,12 +1819,16 @@ __global__ __launch_bounds__(512) void zstep_codes_kernel(float* __restrict__ z,
         const int b0 = wrow0 + rb * 32;
         if (b0 < Bp) {
             float* dst = slab + (size_t)blockIdx.x * Bp * K;
+            const int l16 = lane & 15, q4 = lane >> 4;            // C layout of the 16 x 16 tiles: rows 4 q4 + r, column l16
 #pragma unroll
-            for (int at = 0; at < AT; ++at)
-                if (at * 32 + c < K) {
+            for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dst[(size_t)(b0 + c_row(r, h)) * K + at * 32 + c] = accv[rb][at][r];
-                }
+                for (int nt = 0; nt < NT16; ++nt)
+                    if (nt * 16 + l16 < K) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            dst[(size_t)(b0 + 16 * hf + 4 * q4 + r) * K + nt * 16 + l16] = accv[rb][hf][nt][r];
+                    }
         }
     }
     if (max_abs_delta != nullptr) {

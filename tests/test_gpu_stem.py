@@ -100,6 +100,17 @@ def test_stem_conv_bwd(b, h, w_, dt):
     assert bool((err <= tol).all()), float((err - tol).max())
 
 
+def _bf16_depth_bound(layers: int) -> float:
+    """Mean |logit error| of a bf16-activation network against its fp32 twin, RELATIVE to the rms logit, that the tests
+    below allow.  Model: every activation tensor is stored once in bf16, i.e. with a relative rounding error uniform in
+    +-2^-9 (rms 2^-9 / sqrt(3)); `layers` such roundings in series, propagated with unit relative gain, add in quadrature:
+    rms relative error sqrt(layers) 2^-9 / sqrt(3), mean |.| = 0.8 of that.  The bound 2 * 2^-9 * sqrt(layers) is 4.3 x
+    the model — room for a relative gain above 1 in a random-weight network and for the library's algorithm choices, while a
+    broken epilogue (a wrong scale / shift, a dropped residual) is off by the logits' own size, i.e. 1 in these units.
+    Recorded: ResNet-18 0.0046, ResNet-50 0.0060 against bounds of 0.0175 and 0.0284."""
+    return 2.0 * 2.0 ** -9 * layers ** 0.5
+
+
 def test_fused_stem_resnet_matches_unfused():
     """ResNet-18 with the stem kernels: against the fp32 network (same weights) its logits and input gradient are as
     accurate as the bf16 conv + epilogue path's (both differ from fp32 only by bf16 rounding of activations)."""
@@ -113,8 +124,9 @@ def test_fused_stem_resnet_matches_unfused():
     xr, x0, x1 = (x.float().requires_grad_(True), x.clone().requires_grad_(True), x.clone().requires_grad_(True))
     lr, l0, l1 = ref(xr), m0(x0).float(), m1(x1).float()
     e0, e1 = float((l0 - lr).abs().mean()), float((l1 - lr).abs().mean())
-    print("resnet18 logit error vs fp32: plain bf16 %.4f fused %.4f, rms(logits) %.4f" % (e0, e1, float(lr.square().mean().sqrt())))
-    assert e1 <= 2.0 * e0 + 1e-3, (e0, e1)                    # factor 2: see the ResNet-50 test below
+    rms = float(lr.square().mean().sqrt())
+    print("resnet18 logit error vs fp32: plain bf16 %.4f fused %.4f, rms(logits) %.4f" % (e0, e1, rms))
+    assert e1 <= _bf16_depth_bound(20) * rms, (e0, e1, rms)   # measured 0.0054 at rms 1.17: 0.26 of the bound (plain: 0.0059)
     (gr,) = torch.autograd.grad(lr.square().sum(), xr)
     (g0,) = torch.autograd.grad(l0.square().sum(), x0)
     (g1,) = torch.autograd.grad(l1.square().sum(), x1)
@@ -206,10 +218,11 @@ def test_fused_resnet50_gradient_matches_fp32():
     xr, x0, x1 = (x.float().requires_grad_(True), x.clone().requires_grad_(True), x.clone().requires_grad_(True))
     lr, l0, l1 = ref(xr), m0(x0).float(), m1(x1).float()
     e0, e1 = float((l0 - lr).abs().mean().detach()), float((l1 - lr).abs().mean().detach())
-    print("resnet50 logit error vs fp32: plain bf16 %.4f fused %.4f, rms(logits) %.4f" % (e0, e1, float(lr.square().mean().sqrt())))
-    # both are bf16 networks scored against fp32; which MIOpen algorithms the plain one gets varies with the box, and with it
-    # e0 (0.059 on one box, with e1 = 0.0905: a ratio of 1.53 where 1.5 was asserted) — the guard is a factor 2
-    assert e1 <= 2.0 * e0 + 1e-3, (e0, e1)
+    rms = float(lr.square().mean().sqrt())
+    print("resnet50 logit error vs fp32: plain bf16 %.4f fused %.4f, rms(logits) %.4f" % (e0, e1, rms))
+    # ADVICE r3 / VERDICT r3 #6: an ABSOLUTE bound from a model of bf16 storage, not a ratio to the plain bf16 network (whose
+    # own error moves with the MIOpen algorithms a box picks: 0.059 ... 0.088 recorded, which made a ratio test flaky)
+    assert e1 <= _bf16_depth_bound(53) * rms, (e0, e1, rms)   # measured 0.0905 at rms 15.1: 0.21 of the bound
     (gr,) = torch.autograd.grad(lr.square().sum(), xr)
     (g0,) = torch.autograd.grad(l0.square().sum(), x0)
     (g1,) = torch.autograd.grad(l1.square().sum(), x1)
