@@ -607,7 +607,7 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": (f"ADiL learn_dictionary_a step vs {args.model}, {B} images/GPU, {K} atoms, "
                                 f"{S}x{S}, {args.dtype} image streams + fp32 D/V master"
-                                f"{', fp8 (e4m3) operands in the synthesis contraction' if args.fp8_synth else ''}, loss={args.loss}, "
+                                f"{', fp8 (e4m3) operands in the synthesis contraction, read from the persistent fp8 copy of D that the AdamW launch maintains [measured: no faster than bf16 operands — 86.1 vs 85.8 us per synthesis at 100 atoms, +2.5 us in AdamW(D): the synthesis is bound by its 2 B P s image streams and by occupancy, not by the 45 MB of dictionary the copy saves; a precision variant, not a speed-up]' if args.fp8_synth else ''}, loss={args.loss}, "
                                 + ("clean pseudo-labels computed once per image and cached (1 fwd + 1 bwd per step; result-neutral, "
                                    "profiles/r03_label_stability.md)" if args.cache_labels else
                                    "clean pseudo-labels recomputed in every step (the reference's op sequence, 2 fwd + 1 bwd)"))
