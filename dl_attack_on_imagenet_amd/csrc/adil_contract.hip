@@ -1518,6 +1518,11 @@ __global__ __launch_bounds__(NW * 64) void grad_v_f32_kernel(const float* __rest
         k0 = half ? k_split : 0;
         kn = half ? K - k_split : k_split;
     }
+    // Round 4: the in-wave software pipeline of round 3's ablation (tools/exp/ablate_grad_v_f32.hip, pipe_kernel: bit-identical
+    // slabs, never slower on six boxes, mean -5 %): ONE register stage; a wave reads all A fragments of tile t first, then
+    // the split + ds_write of tile t+1 — into the image rows it has just read, which only this wave ever reads — is
+    // interleaved with the MFMAs of tile t (pinned with sched_barrier: the compiler's own schedule spills), and the loads
+    // of tile t+2 are issued as the registers free up.  Tiles beyond the range are clamped loads against a zeroed D tile.
     using M = Mma<float>;
     using Frag = M::Frag;
     constexpr int TW = 32, KA = AT * 32, NT = NW * 64;
@@ -1525,78 +1530,93 @@ __global__ __launch_bounds__(NW * 64) void grad_v_f32_kernel(const float* __rest
     constexpr int GD = TW + DPAD, DPL = KA * GD, DBUF = 3 * DPL; // D tile planes [2][3][KA][GD]
     constexpr int LPR = TW / 4, RPI = 64 / LPR, NLD = 32 / RPI;
     constexpr int DPT = (TW * KA + NT - 1) / NT;
+    constexpr int NGRP = (TW / 16) * AT;                         // MFMA groups per tile (six MFMAs each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sdt = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* simg = sdt + 2 * DBUF;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int t0 = range * tiles_per_wg;
     const int t1 = min(ntiles, t0 + tiles_per_wg);
-    const int b0 = w * 32;
-    const bool active = b0 < Bp;                                 // waves beyond the batch only help staging D
+    const int tlast = max(t1 - 1, 0);
+    const int b0 = w * 32;                                       // waves beyond the batch stream a clamped row: never stored
     const int lrow = lane / LPR, lcol = (lane - lrow * LPR) * 4;
     f32x16 accv[AT];
 #pragma unroll
     for (int at = 0; at < AT; ++at)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accv[at][r] = 0.0f;
-
-    struct Stage { float dreg[DPT]; u32x4 blk[NLD]; };
-    auto load_stage = [&](Stage& st, int tile) __attribute__((always_inline)) {
+    float dreg[DPT];
+    u32x4 blk[NLD];
+    const float* grow[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int row = b0 + i * RPI + lrow;
+        grow[i] = g + (size_t)(row < B ? row : B - 1) * P + lcol;
+    }
+    auto load_d = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < DPT; ++e) {
             const int i = tid + e * NT;
             const int px = i / KA, a = i - px * KA;
-            st.dreg[e] = d[(size_t)(tile * TW + (px < TW ? px : TW - 1)) * K + k0 + (a < kn ? a : kn - 1)];
-        }
-        if (active) {
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int row = b0 + i * RPI + lrow;
-                st.blk[i] = *reinterpret_cast<const u32x4*>(g + (size_t)(row < B ? row : B - 1) * P + tile * TW + lcol);
-            }
+            dreg[e] = d[(size_t)(tile * TW + (px < TW ? px : TW - 1)) * K + k0 + (a < kn ? a : kn - 1)];
         }
     };
-    auto write_d = [&](bf16_t* dst, const Stage& st) __attribute__((always_inline)) {
+    auto load_img = [&](int i, int tile) __attribute__((always_inline)) {
+        blk[i] = *reinterpret_cast<const u32x4*>(grow[i] + tile * TW);
+    };
+    auto split_img = [&](int i) __attribute__((always_inline)) {
+        const float f4[4] = {__uint_as_float(blk[i][0]), __uint_as_float(blk[i][1]), __uint_as_float(blk[i][2]),
+                             __uint_as_float(blk[i][3])};
+        DImg<float>::put4(simg, (b0 + i * RPI + lrow) * GI + lcol, IPL, f4);
+    };
+    auto write_d = [&](bf16_t* dst, float valid) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < DPT; ++e) {
             const int i = tid + e * NT;
             const int px = i / KA, a = i - px * KA;
-            if (px < TW) DImg<float>::put(dst, a * GD + px, DPL, st.dreg[e] * ((a < kn) ? 1.0f : 0.0f));
+            if (px < TW) DImg<float>::put(dst, a * GD + px, DPL, dreg[e] * ((a < kn) ? valid : 0.0f));
         }
     };
-    Stage sa, sb;
-    if (t0 < t1) load_stage(sa, t0);
-    if (t0 + 1 < t1) load_stage(sb, t0 + 1);
-    if (t0 < t1) write_d(sdt, sa);
+    load_d(min(t0, tlast));
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) load_img(i, min(t0, tlast));
+    write_d(sdt, t0 < t1 ? 1.0f : 0.0f);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) split_img(i);
+    load_d(min(t0 + 1, tlast));
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) load_img(i, min(t0 + 1, tlast));
 
-    auto tile_step = [&](int tile, int dbuf, Stage& cur, Stage& oth) __attribute__((always_inline)) {
-        if (active) {
+    auto tile_step = [&](int tile, int dbuf) __attribute__((always_inline)) {
+        lds_barrier();                                          // D[dbuf] staged by everyone; everyone is done reading D[dbuf^1]
+        const bf16_t* sdb = sdt + dbuf * DBUF;
+        Frag a[TW / 16];
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const float f4[4] = {__uint_as_float(cur.blk[i][0]), __uint_as_float(cur.blk[i][1]),
-                                     __uint_as_float(cur.blk[i][2]), __uint_as_float(cur.blk[i][3])};
-                DImg<float>::put4(simg, (b0 + i * RPI + lrow) * GI + lcol, IPL, f4);
+        for (int g3 = 0; g3 < TW / 16; ++g3) a[g3] = DImg<float>::load8(simg + (b0 + c) * GI + 16 * g3 + 8 * h, IPL);
+        const int tnext = min(tile + 2, tlast);
+        const float valid = tile + 1 < t1 ? 1.0f : 0.0f;
+#pragma unroll
+        for (int q = 0; q < NGRP; ++q) {
+            const int g3 = q / AT, at = q - g3 * AT;
+            M::mma(accv[at], a[g3], DImg<float>::load8(sdb + (at * 32 + c) * GD + 16 * g3 + 8 * h, DPL));
+            // the LDS executes a wave's instructions in order: these writes land after the reads of a[] above
+#pragma unroll
+            for (int i = q * NLD / NGRP; i < (q + 1) * NLD / NGRP; ++i) {
+                split_img(i);
+                load_img(i, tnext);
             }
-        }
-        if (tile + 2 < t1) load_stage(cur, tile + 2);
-        lds_barrier();                                          // D[dbuf] visible; everyone is done reading D[dbuf^1]
-        if (active) {
-            const bf16_t* sdb = sdt + dbuf * DBUF;
-#pragma unroll
-            for (int g3 = 0; g3 < TW / 16; ++g3) {
-                const Frag a = DImg<float>::load8(simg + (b0 + c) * GI + 16 * g3 + 8 * h, IPL);
-#pragma unroll
-                for (int at = 0; at < AT; ++at)
-                    M::mma(accv[at], a, DImg<float>::load8(sdb + (at * 32 + c) * GD + 16 * g3 + 8 * h, DPL));
+            if (q == NGRP - 1) {
+                write_d(sdt + (dbuf ^ 1) * DBUF, valid);
+                load_d(tnext);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (tile + 1 < t1) write_d(sdt + (dbuf ^ 1) * DBUF, oth);
     };
     for (int tile = t0; tile < t1; tile += 2) {
-        tile_step(tile, 0, sa, sb);
-        if (tile + 1 < t1) tile_step(tile + 1, 1, sb, sa);
+        tile_step(tile, 0);
+        tile_step(tile + 1, 1);                                   // an odd range's last step meets a zeroed D tile
     }
-    if (active) {
+    if (b0 < Bp) {
         float* dst = slab + (size_t)range * Bp * K + k0;
 #pragma unroll
         for (int at = 0; at < AT; ++at)
