@@ -70,11 +70,15 @@ def judged(net, adv, in_dtype):
 out = {"runs": []}
 x16, index = images.to(dev).to(torch.bfloat16), torch.arange(n, device=dev)
 lab = engine.predict(fast, x16)
-g = torch.Generator().manual_seed(33)
-d0 = -1 + 2 * torch.rand(3, 224, 224, k, generator=g)
-v0 = O.project_onto_l1_ball(torch.rand(n, k, generator=g), eps)
 bad = None
+# (a first version repeated ONE seed: six runs inside one process gave the identical ASR, 0.990479 — the bf16 pipeline is
+# deterministic within a process; the spread of experiments 1-3 is between processes / boxes (library algorithm choices)
+# and between initialisations.  So: one run per seed.)
+seed0 = int(os.environ.get("SEED0", 4033))
 for run in range(max_runs):
+    g = torch.Generator().manual_seed(seed0 + 1000 * run)
+    d0 = -1 + 2 * torch.rand(3, 224, 224, k, generator=g)
+    v0 = O.project_onto_l1_ball(torch.rand(n, k, generator=g), eps)
     learner = engine.DictionaryLearner(d0.to(dev), v0.to(dev), eps, 0.01, "logits", False, 50.0)
     for _ in range(T):
         learner.step(fast, x16, index, lab)
@@ -85,7 +89,7 @@ for run in range(max_runs):
     adv = attack_all(atk, torch.bfloat16)
     f32, m32 = judged(ref, adv, torch.float32)
     asr = float(f32.float().mean())
-    out["runs"].append(asr)
+    out["runs"].append([seed0 + 1000 * run, asr])
     print(f"run {run}: ASR judged by the fp32 network {asr:.4f}", file=sys.stderr, flush=True)
     if asr < low:
         bad = (name, learner.d.clone(), adv, f32, m32)
