@@ -70,6 +70,11 @@ struct AdamWHyper {
 };
 
 __device__ __forceinline__ float adamw_elem(float p, float g, float& m, float& s, const AdamWHyper& h) {
+    // No FMA contraction in here: the function is inlined into many kernels (and template instantiations of one kernel), and
+    // hipcc's default -ffp-contract=fast fused `s*b2 + (1-b2)*g*g` one way in one of them and another way in the next — the
+    // "same" update then differed in the last bit between two launch routes (round 4: the four-wave and the one-wave form
+    // of adamw_l1ball_kernel).  Every product and sum below is rounded on its own, as torch's AdamW does on the host.
+#pragma clang fp contract(off)
     p *= h.decay;
     m = m + (1.0f - h.b1) * (g - m);                 // exp_avg.lerp_(grad, 1-b1)
     s = s * h.b2 + (1.0f - h.b2) * g * g;            // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
