@@ -72,8 +72,11 @@ struct AdamWHyper {
 __device__ __forceinline__ float adamw_elem(float p, float g, float& m, float& s, const AdamWHyper& h) {
     // No FMA contraction in here: the function is inlined into many kernels (and template instantiations of one kernel), and
     // hipcc's default -ffp-contract=fast fused `s*b2 + (1-b2)*g*g` one way in one of them and another way in the next — the
-    // "same" update then differed in the last bit between two launch routes (round 4: the four-wave and the one-wave form
-    // of adamw_l1ball_kernel).  Every product and sum below is rounded on its own, as torch's AdamW does on the host.
+    // "same" update then differed in the last bit between two launch routes (round 4: a four-wave variant of
+    // adamw_l1ball_kernel against the one-wave form — the variant summed its slabs in one memory round trip instead of
+    // eight and measured no faster, 10.2 vs 10.5 us: the slab reads are bound by their 256-byte access pattern, not by
+    // the round trips; it was removed, this guard stays).  Every product and sum below is rounded on its own, as torch's
+    // AdamW does on the host.
 #pragma clang fp contract(off)
     p *= h.decay;
     m = m + (1.0f - h.b1) * (g - m);                 // exp_avg.lerp_(grad, 1-b1)
@@ -119,52 +122,6 @@ __device__ __forceinline__ float slab_sum(const float* __restrict__ p, int nslab
         for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
     }
     return acc[0];
-}
-
-// The same sum — bit for bit — formed by FOUR waves of a workgroup: wave w owns the accumulators u = w, w+4, ..., w+28 of
-// slab_sum (slab s still goes to accumulator s % 32, in increasing s), so the pairwise tree's levels 16, 8 and 4 stay
-// inside a wave and only levels 2 and 1 cross waves (through `xch`, 4 x 64 floats of LDS).  What it buys: slab_sum walks
-// its rounds of 32 loads one after the other (each round's registers are reused by the next: ~8 dependent memory round
-// trips for the ~240 slabs of a 512-image batch, 10 us of pure latency in pack_codes), while here a wave has only 8 values
-// per round and requests EIGHT rounds at once (64 loads in flight per lane): one round trip per 256 slabs.
-// All four waves of the workgroup must call it (it contains a barrier); every lane of wave 0 returns the sum of its entry,
-// the other waves return a partial value that must not be used.  lane = lane in the wave, w = wave in the workgroup.
-__device__ __forceinline__ float slab_sum_coop4(const float* __restrict__ p, int nslabs, size_t stride, int w, int lane,
-                                                float* xch) {
-    float acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
-    const int full = nslabs & ~31;                                // slabs covered by whole rounds of 32
-    for (int r0 = 0; r0 < nslabs; r0 += 256) {                    // eight rounds per pass
-        float t[8][8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int s = r0 + 32 * r + w + 4 * i;
-                t[r][i] = p[(size_t)(s < nslabs ? s : nslabs - 1) * stride];
-            }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int s0 = r0 + 32 * r;
-            if (s0 + 32 <= full) {                                 // a whole round: plain adds, as slab_sum
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] += t[r][i];
-            } else if (s0 < nslabs) {                              // the tail round: clamped loads times a 0/1 weight, as slab_sum
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] += ((s0 + w + 4 * i < nslabs) ? 1.0f : 0.0f) * t[r][i];
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] += acc[i + 4];             // tree level 16: acc[u] += acc[u + 16]
-    acc[0] += acc[2]; acc[1] += acc[3];                           // level 8
-    acc[0] += acc[1];                                             // level 4: this wave now holds slab_sum's acc[w]
-    xch[w * 64 + lane] = acc[0];
-    __syncthreads();
-    const float a0 = xch[lane], a1 = xch[64 + lane], a2 = xch[128 + lane], a3 = xch[192 + lane];
-    __syncthreads();                                              // xch may be reused by the caller's next sum
-    return (a0 + a2) + (a1 + a3);                                 // levels 2 and 1
 }
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }

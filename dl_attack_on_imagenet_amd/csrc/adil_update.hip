@@ -124,7 +124,7 @@ __device__ __forceinline__ void l1ball_row(float (&x)[EPL], int lane, float radi
 }
 
 // ---- K5: AdamW on all N rows of V + l1-ball projection --------------------- //
-template <int EPL, bool COOP = false>
+template <int EPL>
 __global__ __launch_bounds__(256) void adamw_l1ball_kernel(float* __restrict__ v, const float* __restrict__ grad_vb,
                                                            int32_t* __restrict__ pos, float* __restrict__ m,
                                                            float* __restrict__ s, int N, int K, AdamWHyper h,
@@ -141,32 +141,13 @@ __global__ __launch_bounds__(256) void adamw_l1ball_kernel(float* __restrict__ v
     }
     if (clear != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *clear = 0.0f;
     const int lane = threadIdx.x & 63;
-    // COOP (slab gradients, round 4): one ROW per workgroup of four waves; waves 1-3 only help wave 0 sum the row's
-    // gradient from the producer's slabs (slab_sum_coop4: the same bits as slab_sum in one memory round trip instead of
-    // eight) and leave; wave 0 owns the row as before
-    const int wv = COOP ? (int)(threadIdx.x >> 6) : 0;
-    const int row = COOP ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    if (row >= N) return;                          // whole workgroup (COOP) / wave exits together
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= N) return;                          // whole wave exits together
     int slot = row;
-    if (pos != nullptr) slot = pos[row];
-    if constexpr (COOP) {
-        if (pos != nullptr && reset_pos) __syncthreads();        // every wave has read pos[row] before wave 0 resets it
-    }
-    // one wave owns the row: hand the slot table back all -1 for the next batch's adil_pack_codes
-    if (pos != nullptr && reset_pos && slot >= 0 && lane == 0 && wv == 0) pos[row] = -1;
-    float gsum[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) gsum[e] = 0.0f;
-    if constexpr (COOP) {
-        __shared__ float xch[256];
-        if (do_adam && slot >= 0) {                              // uniform over the workgroup
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int k = e * ADIL_WAVE + lane;
-                gsum[e] = slab_sum_coop4(slabs + (size_t)slot * K + (k < K ? k : K - 1), nslabs, (size_t)slab_rows * K, wv, lane, xch);
-            }
-        }
-        if (wv != 0) return;
+    if (pos != nullptr) {
+        slot = pos[row];
+        // one wave owns the row: hand the slot table back all -1 for the next batch's adil_pack_codes
+        if (reset_pos && slot >= 0 && lane == 0) pos[row] = -1;
     }
     float x[EPL], x_old[EPL];
 #pragma unroll
@@ -183,9 +164,8 @@ __global__ __launch_bounds__(256) void adamw_l1ball_kernel(float* __restrict__ v
                 // order of slab_sum: the reduction launch between adil_grad and this kernel is gone)
                 float g = 0.0f;
                 if (slot >= 0)
-                    g = COOP ? gsum[e]
-                             : (nslabs > 0) ? slab_sum(slabs + (size_t)slot * K + k, nslabs, (size_t)slab_rows * K)
-                                            : grad_vb[(size_t)slot * K + k];
+                    g = (nslabs > 0) ? slab_sum(slabs + (size_t)slot * K + k, nslabs, (size_t)slab_rows * K)
+                                     : grad_vb[(size_t)slot * K + k];
                 val = adamw_elem(val, g, mm, ss, h);
                 m[i] = mm; s[i] = ss;
             }
@@ -254,29 +234,18 @@ __global__ __launch_bounds__(256) void pack_codes_kernel(const float* __restrict
                                                          int32_t* __restrict__ pos, E* __restrict__ vpt, int A,
                                                          const float* __restrict__ slabs, int nslabs, int slab_rows) {
     const int W = (vpt != nullptr) ? A : Kp;                       // A >= Kp always
-    // rows from slabs: workgroups of four waves, 64 entries each, the four waves summing the same 64 entries together
-    // (slab_sum_coop4, round 4); waves 1-3 leave once the sums are formed.  Otherwise one entry per thread.
-    const bool coop = nslabs > 0;
-    const int i = coop ? (int)(blockIdx.x * 64 + (threadIdx.x & 63)) : (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Bp * W) return;
+    const int b = i / W, k = i - b * W;
     float val = 0.0f;
-    int b = 0, k = 0;
-    if (coop) {
-        __shared__ float xch[256];
-        const int ic = i < Bp * W ? i : Bp * W - 1;               // every lane takes part in the workgroup's barrier
-        b = ic / W; k = ic - b * W;
-        const bool real = b < B && k < K;
-        const float sum = slab_sum_coop4(slabs + (size_t)(real ? b : 0) * K + (real ? k : 0), nslabs, (size_t)slab_rows * K,
-                                         (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), xch);
-        if ((threadIdx.x >> 6) != 0 || i >= Bp * W) return;
-        val = real ? sum : 0.0f;
-    } else {
-        if (i >= Bp * W) return;
-        b = i / W; k = i - b * W;
-    }
-    if (!coop && b < B && k < K) {
-        const int64_t row = (index != nullptr) ? index[b] : (int64_t)b;
-        val = v[row * K + k];
-        if (k == 0 && pos != nullptr) pos[row] = b;         // batch slot of code row `row` (consumed + reset by K5)
+    if (b < B && k < K) {
+        if (nslabs > 0) {
+            val = slab_sum(slabs + (size_t)b * K + k, nslabs, (size_t)slab_rows * K);
+        } else {
+            const int64_t row = (index != nullptr) ? index[b] : (int64_t)b;
+            val = v[row * K + k];
+            if (k == 0 && pos != nullptr) pos[row] = b;     // batch slot of code row `row` (consumed + reset by K5)
+        }
     }
     if (k < Kp) vp[(size_t)b * Kp + k] = val;
     if (vpt != nullptr) {
@@ -550,8 +519,8 @@ extern "C" int adil_pack_codes(const float* v, const int64_t* index, int B, int 
     if (nslabs < 0 || (vpt != nullptr && ((uintptr_t)vpt & 15))) return ADIL_EINVAL;
     const int Kp = round_up(K, 16), Bp = round_up(B, 32), A = adil_grad_code_rows(K);
     const int total = Bp * (vpt != nullptr ? A : Kp);
-    const int per_block = nslabs > 0 ? 64 : 256;                 // slab sums: 64 entries per workgroup, its four waves share them
-    const dim3 grid((total + per_block - 1) / per_block), block(256);
+    const int threads = nslabs > 0 ? 64 : 256;                   // slab sums: spread the latency-bound lanes over all CUs
+    const dim3 grid((total + threads - 1) / threads), block(threads);
     hipStream_t st = (hipStream_t)stream;
     if (vpt == nullptr || vpt_dtype == ADIL_F32)
         hipLaunchKernelGGL(pack_codes_kernel<float>, grid, block, 0, st, v, index, B, K, Kp, Bp, vp, pos, (float*)vpt, A, slabs,
@@ -652,26 +621,15 @@ static int launch_adamw_l1ball(float* v, const float* grad_vb, int32_t* pos, flo
                                hipStream_t st, const float* skip_if_below = nullptr, float skip_threshold = 0.0f,
                                float* clear = nullptr, const float* dyn = nullptr, const float* slabs = nullptr,
                                int nslabs = 0, int slab_rows = 0) {
-    // one wave per row (four rows per workgroup); with the slab reduction inside: one ROW per workgroup, its four waves
-    // sharing the sum (slab_sum_coop4)
-    if (nslabs > 0) {                                            // one row per workgroup, four waves sum its slabs together
-        const dim3 grid(N), block(256);
-        if (K <= 64)
-            hipLaunchKernelGGL((adamw_l1ball_kernel<1, true>), grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
-                               max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear, dyn, slabs, nslabs, slab_rows);
-        else
-            hipLaunchKernelGGL((adamw_l1ball_kernel<2, true>), grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
-                               max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear, dyn, slabs, nslabs, slab_rows);
-        ADIL_CHECK_LAUNCH();
-        return 0;
-    }
-    const int rows_per_block = 4;
+    // one wave per row; with the slab reduction inside, one wave per WORKGROUP: the batch rows each walk ~240 slabs in
+    // dependent rounds of 32 loads, and 512 single-wave workgroups spread over all CUs where 128 four-wave ones fill half
+    const int rows_per_block = nslabs > 0 ? 1 : 4;
     const dim3 grid((N + rows_per_block - 1) / rows_per_block), block(64 * rows_per_block);
     if (K <= 64)
-        hipLaunchKernelGGL((adamw_l1ball_kernel<1, false>), grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
+        hipLaunchKernelGGL(adamw_l1ball_kernel<1>, grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
                            max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear, dyn, slabs, nslabs, slab_rows);
     else
-        hipLaunchKernelGGL((adamw_l1ball_kernel<2, false>), grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
+        hipLaunchKernelGGL(adamw_l1ball_kernel<2>, grid, block, 0, st, v, grad_vb, pos, m, s, N, K, h, radius,
                            max_abs_delta, do_adam, reset_pos, skip_if_below, skip_threshold, clear, dyn, slabs, nslabs, slab_rows);
     ADIL_CHECK_LAUNCH();
     return 0;
