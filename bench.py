@@ -355,7 +355,8 @@ def bench_transfer(args, rank, world, dev, timer):
     shape, P, eps = (3, S, S), 3 * S * S, 8 / 255
     fused = bool(args.fuse_bn_act) and zoo.canonical_name(args.model).startswith("resnet")
     source = zoo.build_classifier(args.model, seed=0, device=dev, dtype=sdtype, channels_last=bool(args.channels_last) and fused,
-                                  fuse_bn_act=fused, fuse_stem=bool(args.fuse_stem and fused and args.dtype == "bf16"))
+                                  fuse_bn_act=fused, fuse_stem=bool(args.fuse_stem and fused and args.dtype == "bf16"),
+                                  head_fp32="inference" if (fused and args.dtype == "bf16") else False)
     targets = {name: zoo.build_classifier(name, seed=1 + i, device=dev, dtype=sdtype) for i, name in enumerate(TRANSFER_TARGETS)}
     tmp = tempfile.mkdtemp(prefix=f"adil_bench_rank{rank}_")
     gd0 = torch.Generator().manual_seed(7)                           # the same dictionary on every rank (one learned D, replicated)
@@ -406,7 +407,7 @@ def bench_transfer(args, rank, world, dev, timer):
                                 f"loss={args.loss}) against {args.model}, adversary scored on {len(targets)} targets "
                                 f"({', '.join(targets)}), {B} images per batch, {args.steps} batches per GPU, {S}x{S}, {args.dtype} "
                                 f"image streams, fp32 z + AdamW moments; evaluation set resident in HBM (loader.ResidentBatches)"),
-                   "classifier": f"random-init {args.model} (source{', FusedResNet' if fused else ''}) and six random-init targets, frozen, eval",
+                   "classifier": f"random-init {args.model} (source{', FusedResNet with fp32 logits inside the DDrague loop (head_fp32=inference)' if fused else ''}) and six random-init targets, frozen, eval",
                    "global_batch": world * B, "atoms": K, "steps_inference": args.steps_inference,
                    "ddrague_iterations_run_per_batch": iters_run,
                    "parallelism": f"dp{world}: batches dealt to ranks (performance.py path), D replicated, final sums all-reduced",
@@ -512,7 +513,11 @@ def main():
                                  fold_bn=bool(args.fold_bn), pad_input_channels=args.pad_cin,
                                  fuse_bn_act=bool(args.fuse_bn_act),
                                  fuse_stem=bool(args.fuse_stem and args.fuse_bn_act and args.dtype == "bf16"
-                                                and zoo.canonical_name(args.model).startswith("resnet")))
+                                                and zoo.canonical_name(args.model).startswith("resnet")),
+                                 # the bf16 FusedResNet's logits in fp32 INSIDE the DDrague inference loop only (engine.precise_head;
+                                 # the learner keeps the bf16 head): +1.5 ... 2.5 pp ASR at no cost, profiles/r04_asr_gap.md
+                                 head_fp32="inference" if (args.fuse_bn_act and args.dtype == "bf16"
+                                                           and zoo.canonical_name(args.model).startswith("resnet")) else False)
     gen = torch.Generator().manual_seed(1000 + rank)                 # each rank owns different images (weak scaling)
     x = torch.rand(B, *shape, generator=gen).to(dev).to(sdtype).contiguous()
     gd0 = torch.Generator().manual_seed(7)                           # the same D0 on every rank
@@ -619,7 +624,8 @@ def main():
                                  f"bn_act_epilogue_fused={args.fuse_bn_act}, bn_folded={args.fold_bn}, "
                                  f"first_conv_cin_padded_to={args.pad_cin} (unused with stem kernels), stem_kernels={args.fuse_stem}, "
                                  f"pointwise_convs=fused GEMM+epilogue kernels (fwd and input gradient), "
-                                 f"stride1_3x3_convs=adil_conv3x3",
+                                 f"stride1_3x3_convs=adil_conv3x3, head=bf16 while learning / fp32 logits inside the DDrague "
+                                 f"inference loop (zoo head_fp32='inference')",
                    "global_batch": world * B, "atoms": K, "inner_iters": args.steps,
                    "parallelism": f"dp{world}: images+codes sharded, D replicated, 1 all-reduce(grad_d)/step",
                    "collective": collective,

@@ -118,7 +118,8 @@ def main(args):
     if structured and weights is None:
         weights = _fitted_weights(model_name, args.seed, train_dataset, n_classes, device)
     model = zoo.build_classifier(model_name, seed=args.seed, weights=weights, device=device, dtype=dtype,
-                                 channels_last=fast, fuse_bn_act=fast, fuse_stem=fast)
+                                 channels_last=fast, fuse_bn_act=fast, fuse_stem=fast,
+                                 head_fp32="inference" if fast else False)      # fp32 logits inside the DDrague inference loop
     if args.clean_accuracy:                                                               # demo_dL_attack.py:65-66
         from model_accuracy import model_accuracy, model_accuracy_distributed
         dataset.indexed = False

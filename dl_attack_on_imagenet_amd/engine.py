@@ -95,6 +95,24 @@ def _classify(model, x: Tensor) -> Tensor:
     return out if xp is x else out[:x.shape[0]]
 
 
+class precise_head:
+    """Context manager: while it is in force, classifiers that carry an optional higher-precision head (zoo.FusedResNet built
+    with head_fp32="inference") use it.  The DDrague inference solver wraps its classifier calls in it; any other model is
+    left alone."""
+
+    def __init__(self, model, enabled: bool = True):
+        self.parts = [m for m in model.modules() if hasattr(m, "precise_head")] if hasattr(model, "modules") else []
+        self.enabled, self.prev = enabled, []
+
+    def __enter__(self):
+        self.prev = [m.precise_head(self.enabled) for m in self.parts]
+        return self
+
+    def __exit__(self, *exc):
+        for m, p in zip(self.parts, self.prev):
+            m.precise_head(p)
+
+
 @torch.no_grad()
 def predict(model, x: Tensor) -> Tensor:
     return _classify(model, x).argmax(dim=-1)
@@ -474,7 +492,8 @@ class DDragueSolver:
         self.iters += 1
         vp = self.packed_codes()                                                         # adil.py:542
         xt = ops.synth(self.images, self.d, vp, b)                                       # adil.py:543-544
-        _, _, g = input_gradient(self.model, xt, self.labels, self.loss, self.coeff, self.kappa, "mean")
+        with precise_head(self.model):                                                   # fp32 logits where the classifier offers them
+            _, _, g = input_gradient(self.model, xt, self.labels, self.loss, self.coeff, self.kappa, "mean")
         _, gv = ops.grad(g, self.d, None, b, want_d=False, want_v=True, defer_v=True)    # dL/dv = g D (summed by pack_codes)
         # dL/dz = (dL/dv) D_dagger is formed inside the kernel and consumed by AdamW(z) + clamp: never materialised (K8)
         gvp = ops.pack_codes(gv, None, b)

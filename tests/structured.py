@@ -42,7 +42,9 @@ def fitted_classifiers(name, images, labels, classes, device, tmp_dir, seed=0, t
     path = os.path.join(str(tmp_dir), f"{name}_fitted.pt")
     torch.save(ref[-1].state_dict(), path)
     fused = zoo.canonical_name(name).startswith("resnet")
+    # the product's configuration: bf16 head while learning, fp32 logits inside the DDrague inference loop (round 4)
     fast = zoo.build_classifier(name, seed=seed, weights=path, device=device, dtype=torch.bfloat16, channels_last=fused,
+                                head_fp32="inference" if fused else False,
                                 fuse_bn_act=fused, fuse_stem=fused)
     ref = zoo.build_classifier(name, seed=seed, weights=path, device=device)
     return ref, fast, margins, pred

@@ -250,8 +250,9 @@ def test_asr_parity_bf16_product_vs_fp32_reference_structured(structured, tmp_pa
       A  the fp32 REFERENCE CONFIGURATION: fp32 oracle learner + oracle inference + plain fp32 ResNet-50 (2048 of the images:
          the fp32 network is the slow part of this test)
       C  the PRODUCT as benchmarked: DictionaryLearner (HIP kernels, bf16 streams) + ADIL.forward + the bf16 FusedResNet
-         (the same weights); every adversarial batch judged TWICE — by the network under attack (what performance.py
-         computes) and by the plain fp32 network (the classifier the reference attacks; VERDICT r3 #1a)
+         (the same weights; its logits in fp32 inside the DDrague inference loop only: zoo head_fp32="inference", the
+         switch round 4's experiments selected); every adversarial batch judged TWICE — by the network under attack (what
+         performance.py computes) and by the plain fp32 network (the classifier the reference attacks; VERDICT r3 #1a)
     What is ASSERTED, and what round 4's experiments say about the rest (profiles/r04_asr_gap.md, tests/experiments/
     exp_asr_gap*.py; 4096 held-out images per figure):
       * fp32 tolerance, north_star's +-0.5 pp: on the SAME dictionary the oracle's inference and the product's inference
@@ -266,12 +267,15 @@ def test_asr_parity_bf16_product_vs_fp32_reference_structured(structured, tmp_pa
         93.99 % (two thirds at or above A - 0.5, one third 1-5 pp below; mean 98.1).  A bad run loses ONE class (experiment 4:
         234 of the 246 unfooled images belong to one of the ten classes; the same dictionary fools that class against the
         fp32 network: 99.2 %).  fp32 image streams into the bf16 network change
-        nothing (98.00 vs 98.00 % over four dictionaries, paired); the classifier head in fp32 (zoo head_fp32) at inference
-        gains 1.0 pp paired (99.04 +- 0.79 %) but used for learning as well it is tighter AND lower (97.9 +- 0.6 %); the
-        oracle's fp32 inference on the product's dictionary fools 100 % where the product's own bf16 inference fools
-        98.5 %: what is lost is lost by the bf16 classifier inside the inference loop, not by the streams, the kernels or
-        the dictionary.  So the leg is REPORTED with a floor only: a 0.5 pp assertion on a quantity whose run-to-run
-        standard deviation is 2.1 pp would be a coin flip, and the 2 pp guard of round 3 fails one run in five.
+        nothing (98.00 vs 98.00 % over four dictionaries, paired); the classifier's logits in fp32 INSIDE THE INFERENCE
+        LOOP gain 1.0-2.5 pp paired over eleven dictionaries at no cost — adopted: C is now 98.3 +- 0.8 % (97.4 ... 99.6) —
+        while the fp32 head used for learning as well gives tighter AND lower results (97.9 +- 0.6 %); the three library
+        convolutions of the network (stride-2 3x3, MIOpen) computed in fp32 gain another 2.1 pp (95.6 -> 97.7 % on one
+        seed) at three times the step time: not a product path; the oracle's fp32 inference on the product's dictionary
+        fools 100 % where the product's own bf16 inference fools 98.5 %: what is lost is lost by the bf16 classifier
+        inside the inference loop, not by the streams, the kernels or the dictionary.  So the leg is REPORTED with a floor
+        only: a 0.5 pp assertion on a quantity whose run-to-run standard deviation is 0.8 pp (2.1 before the switch) would
+        be a coin flip, and the 2 pp guard of round 3 failed one run in five.
     The fooled-count lists of both learners are printed."""
     import performance as perf
     from attacks import ADIL
@@ -329,9 +333,9 @@ def test_asr_parity_bf16_product_vs_fp32_reference_structured(structured, tmp_pa
     assert abs(perf_a_with_dc["fooling_rate"] - perf_p32["fooling_rate"]) <= 0.005, (perf_a_with_dc, perf_p32)   # measured 0.0 pp
     # the two judges of the bf16 product's adversaries
     assert abs(asr_c16 - asr_c32) <= 0.015, (asr_c16, asr_c32)                                   # measured 0.0-0.9 pp
-    # the bf16 configuration end to end: reported (docstring); the floor is below mean - 3 sigma of the thirteen recorded
-    # runs (98.1 - 3 x 2.1 = 91.8 %) — a broken kernel or solver misses it by tens of points, not by five
-    assert asr_c32 >= 0.90 and asr_c16 >= 0.90, (asr_c16, asr_c32, perf_a)
+    # the bf16 configuration end to end: reported (docstring); the floor is below mean - 3 sigma of the eleven recorded runs
+    # of this configuration (98.3 - 3 x 0.8 = 95.9 %) — a broken kernel or solver misses it by tens of points, not by three
+    assert asr_c32 >= 0.95 and asr_c16 >= 0.95, (asr_c16, asr_c32, perf_a)
     assert abs(perf_a["rmse"] - rmse_c) <= 0.05 * perf_a["rmse"]
 
 
