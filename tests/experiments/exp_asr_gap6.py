@@ -78,11 +78,13 @@ def pipeline(net, seed, name):
     x16, index = images.to(dev).to(torch.bfloat16), torch.arange(n, device=dev)
     lab = engine.predict(net, x16)
     learner = engine.DictionaryLearner(d0.to(dev), v0.to(dev), eps, 0.01, "logits", False, 50.0)
+    import time
+    t0 = time.time()
     for it in range(T):
         learner.step(net, x16, index, lab)
         if it % 50 == 49:
             torch.cuda.synchronize()
-            print(f"  {name}: learning iteration {it + 1}", file=sys.stderr, flush=True)
+            print(f"  {name}: learning iteration {it + 1}, {(time.time() - t0) / (it + 1) * 1e3:.2f} ms per step so far", file=sys.stderr, flush=True)
     torch.save([learner.d.cpu(), learner.v.cpu(), [], [], torch.tensor(0.)], os.path.join(tmp, f"ImageNet_{name}.bin"))
     atk = ADIL(net, eps=eps, n_atoms=k, attack="supervised", model_name=name, loss="logits", steps_inference=S, dict_dir=tmp,
                stream_dtype=torch.bfloat16)
@@ -101,10 +103,13 @@ for seed in seeds:
     print(f"seed {seed}: default ...", file=sys.stderr, flush=True)
     fast = zoo.build_classifier("resnet50", **kw)
     rec["default"] = pipeline(fast, seed, f"a{seed}")
-    wide = zoo.build_classifier("resnet50", **kw)
-    rec["widened_convs"] = widen_stride2(wide)
-    rec["s2_fp32"] = pipeline(wide, seed, f"b{seed}")
+    if "s2_fp32" in os.environ.get("VARIANTS", "default,s2_fp32"):
+        wide = zoo.build_classifier("resnet50", **kw)
+        rec["widened_convs"] = widen_stride2(wide)
+        rec["s2_fp32"] = pipeline(wide, seed, f"b{seed}")
+        del wide
+    rec["miopen_env"] = {k_: v_ for k_, v_ in os.environ.items() if k_.startswith("MIOPEN_")}
     out["runs"].append(rec)
     print(json.dumps(rec), file=sys.stderr, flush=True)
-    del fast, wide
+    del fast
 print(json.dumps(out))
