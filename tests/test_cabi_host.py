@@ -400,3 +400,45 @@ def test_structured_synthetic_dataset_is_seeded_and_separable():
     assert float((x0 - x1).abs().mean()) < float((x0 - x50).abs().mean())
     flat = SyntheticImageNet(num_classes=3, samples_per_class=50, size=32, seed=2)
     assert flat.prototypes is None and not torch.equal(flat[0][0], x0)
+
+
+def test_fp32_head_keeps_its_bits_and_the_switch_restores():
+    """zoo._Fp32Head (round 4): the fp32 copy of the last linear layer survives `.to(bfloat16)` bit for bit and yields fp32
+    logits; engine.precise_head switches it on for networks that have it (FusedResNet built with head_fp32="inference"),
+    restores the previous state on exit — also when nested or left through an exception — and ignores other models."""
+    import torch
+    from dl_attack_on_imagenet_amd import engine, zoo
+    torch.manual_seed(0)
+    fc = torch.nn.Linear(16, 5)
+    head = zoo._Fp32Head(fc).to(torch.bfloat16)
+    assert head.weight.dtype == torch.float32 and torch.equal(head.weight, fc.weight.detach())
+    feats = torch.randn(3, 16, 4, 4).to(torch.bfloat16)
+    out = head(feats)
+    assert out.dtype == torch.float32
+    ref = torch.nn.functional.linear(feats.float().mean(dim=(2, 3)), fc.weight, fc.bias)
+    assert torch.allclose(out, ref, atol=1e-6)
+    net = zoo._BUILDERS["resnet18"](10)
+    fused = zoo.FusedResNet(net, head_fp32="inference")
+    model = torch.nn.Sequential(fused)
+    assert fused.head32 is not None and not fused.head32_on
+    with engine.precise_head(model):
+        assert fused.head32_on
+        with engine.precise_head(model, False):
+            assert not fused.head32_on
+        assert fused.head32_on
+    assert not fused.head32_on
+    try:
+        with engine.precise_head(model):
+            raise RuntimeError("x")
+    except RuntimeError:
+        pass
+    assert not fused.head32_on
+    always = zoo.FusedResNet(zoo._BUILDERS["resnet18"](10), head_fp32=True)
+    assert always.head32_on
+    plain = zoo.FusedResNet(zoo._BUILDERS["resnet18"](10))
+    assert plain.head32 is None and plain.precise_head(True) is False and not plain.head32_on
+    with engine.precise_head(torch.nn.Linear(2, 2)):
+        pass
+    import pytest
+    with pytest.raises(ValueError):
+        zoo.FusedResNet(zoo._BUILDERS["resnet18"](10), head_fp32="sometimes")

@@ -778,6 +778,44 @@ def test_ddrague_codes_from_the_zstep_match_the_separate_contraction():
     assert torch.equal(solver.result()[0], adv_f)
 
 
+def test_precise_head_is_entered_by_the_inference_solver_only():
+    """zoo.build_classifier(head_fp32="inference") + engine.precise_head (round 4): the bf16 FusedResNet computes its logits in
+    fp32 (pooling + last linear layer, fp32 weights kept under the bf16 cast) exactly inside the DDrague solver's classifier
+    calls — eager and replayed from a hipGraph alike — and nowhere else: not in the learner's step, not in a plain call (what
+    performance.py's scoring does).  The two heads agree to bf16 rounding of the logits."""
+    from dl_attack_on_imagenet_amd import engine, ops, zoo
+    kw = dict(num_classes=10, seed=3, device=DEV, dtype=torch.bfloat16, channels_last=True, fuse_bn_act=True, fuse_stem=True)
+    net = zoo.build_classifier("resnet18", head_fp32="inference", **kw)
+    fused = net[0]
+    assert fused.head32 is not None and fused.head32.weight.dtype == torch.float32 and fused.fc.weight.dtype == torch.bfloat16
+    calls = {"n": 0}
+    fused.head32.register_forward_hook(lambda *a: calls.__setitem__("n", calls["n"] + 1))
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(8, 3, 64, 64, generator=g).to(DEV).to(torch.bfloat16)
+    plain = net(x)
+    assert plain.dtype == torch.bfloat16 and calls["n"] == 0
+    with engine.precise_head(net):
+        sharp = net(x)
+        with engine.precise_head(net, False):                      # nests and restores
+            assert net(x).dtype == torch.bfloat16
+        assert fused.head32_on
+    assert sharp.dtype == torch.float32 and calls["n"] == 1 and not fused.head32_on
+    assert float((sharp - plain.float()).abs().max()) <= 2.0 ** -7 * float(sharp.abs().max()) + 1e-3   # one bf16 rounding of the logits
+    d = (-1 + 2 * torch.rand(3, 64, 64, 6, generator=g)).to(DEV)
+    v = ops.l1ball_project_(torch.rand(8, 6, generator=g).to(DEV), 0.1)
+    learner = engine.DictionaryLearner(d.clone(), v, 0.1, 0.01, "logits")
+    before = calls["n"]
+    learner.step(net, x, torch.arange(8, device=DEV))
+    assert calls["n"] == before                                     # the learner keeps the bf16 head
+    eager = engine.DDragueSolver(net, x, d, 0.1, "logits").run(9)
+    assert calls["n"] == before + 9                                 # once per inference iteration
+    graphed = engine.DDragueSolver(net, x, d, 0.1, "logits").run(9, use_graph=True)
+    assert torch.equal(eager.result()[0], graphed.result()[0]) and not fused.head32_on
+    # a classifier without the switch is left alone
+    with engine.precise_head(torch.nn.Linear(3, 2)):
+        pass
+
+
 @pytest.mark.parametrize("graph", [1, 0])
 def test_main_cli_one_image_attack(graph, tmp_path, monkeypatch):
     """main.py end to end (the reference's one-image demo, main.py:29-100): default classifier (mobilenet_v2), the
