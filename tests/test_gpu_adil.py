@@ -818,7 +818,8 @@ def test_precise_head_is_entered_by_the_inference_solver_only():
     assert not fused.head32_on and graphed.iters == 9
     for adv in (adv_e, adv_g):
         assert bool(torch.isfinite(adv.float()).all()) and float(adv.min()) >= 0.0 and float(adv.max()) <= 1.0
-    assert float((adv_e.float() - adv_g.float()).abs().max()) <= 2 * 0.1 + 1e-2      # both within the budget of the same images
+    # both perturb the same images by D D_dagger z with |z| <= eps = 0.1 (the perturbation itself may exceed eps: quirk Q6)
+    assert float((adv_e.float() - adv_g.float()).abs().max()) <= 0.6
     # a classifier without the switch is left alone
     with engine.precise_head(torch.nn.Linear(3, 2)):
         pass
