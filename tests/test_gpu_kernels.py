@@ -507,14 +507,15 @@ def test_zstep_fused_vs_unfused(shape):
 
 
 @pytest.mark.parametrize("shape", [(512, 3, 32, 32, 50), (500, 3, 16, 16, 64), (33, 3, 16, 16, 10), (300, 3, 16, 24, 100),
-                                   (600, 3, 16, 16, 50), (70, 3, 16, 8, 112), (16, 3, 224, 224, 50)])
+                                   (600, 3, 16, 16, 50), (70, 3, 16, 8, 112), (16, 3, 224, 224, 50), (512, 3, 224, 224, 100)])
 def test_zstep_codes_fused_with_next_codes(shape):
     """adil_zstep_codes (ABI 7): the z-step that also contracts the updated z with D_dagger^T.  (i) z, m, s and max|dz| are
     the bits of adil_zstep on the same inputs (same arithmetic, other workgroup shape); (ii) the codes pack_codes sums from
     its slabs equal z_new D_dagger^T of an fp64 matmul to fp32-grade tolerance (the fixed-order slab sums make them
     bitwise reproducible); (iii) a launch the device-side stop test skips leaves z AND the slabs untouched.  One / two
     blocks per wave, ragged rows, a second row range of workgroups (600 rows), all three atom tilings, one and several
-    slices per workgroup (224 x 224: 1176 slices)."""
+    slices per workgroup (224 x 224: 1176 slices), and the inference bench's own size at the reference's atom count
+    (512 images, 100 atoms: two row ranges of workgroups, 236 slabs)."""
     b, c, h, w, k = shape
     o = ops()
     p = c * h * w
