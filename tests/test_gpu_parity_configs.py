@@ -288,7 +288,7 @@ def test_asr_parity_bf16_product_vs_fp32_reference_structured(structured, tmp_pa
     from structured import structured_images
     n, k, T, S = 512, 50, STRUCTURED_T, 100
     images, ref, fast = structured["images"], structured["ref"], structured["fast"]
-    n_eval, n_a, n_x, bs = 4096, 2048, 1024, 512
+    n_eval, n_a, n_x, bs = 4096, 2048, 512, 512       # n_x: one batch suffices for the same-dictionary check (0.0 pp in every recorded run)
     held, held_labels = structured_images(n_eval, classes=10, seed=3, draw=1)
     g = torch.Generator().manual_seed(33)
     d0 = -1 + 2 * torch.rand(3, 224, 224, k, generator=g)

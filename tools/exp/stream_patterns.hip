@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void linear(const u32x4* __restrict__ x, u32x4
 #define CK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(r_), __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
-    const int B = 512, P = 150528, NBUF = 6, REP = argc > 1 ? atoi(argv[1]) : 36;
+    const int REP = argc > 1 ? atoi(argv[1]) : 36, B = argc > 2 ? atoi(argv[2]) : 512, P = 150528;
+    const int NBUF = B <= 512 ? 6 : 3;            // >= 1.8 GB in rotation either way
     const size_t n = (size_t)B * P, bytes = n * 2;
     std::vector<bf16_t*> xs(NBUF), os(NBUF);
     for (int i = 0; i < NBUF; ++i) { CK(hipMalloc(&xs[i], bytes)); CK(hipMalloc(&os[i], bytes)); CK(hipMemset(xs[i], 0x3c, bytes)); }
@@ -115,7 +116,7 @@ int main(int argc, char** argv) {
         printf("| %-58s | %7.1f us | %5.2f TB/s |\n", name, us, 2.0 * bytes / (us * 1e-6) / 1e12);
         fflush(stdout);
     };
-    printf("| pattern (B = 512 x P = 150528 bf16, out = x + 1, 154 MB in + 154 MB out) | time | bytes / time |\n|---|---|---|\n");
+    printf("| pattern (B = %d x P = 150528 bf16, out = x + 1, %.0f MB in + %.0f MB out) | time | bytes / time |\n|---|---|---|\n", B, bytes / 1e6, bytes / 1e6);
     for (int pass = 0; pass < 2; ++pass) {
         run("v0  8 B/lane, 256 B rows, 2 rows/instr, tile 128 (now)", [&](int i) {
             hipLaunchKernelGGL((sweep<8, 32>), dim3(P / 128, 1), dim3(256), lds, 0, xs[i], os[i], B, P, B); });
