@@ -638,6 +638,9 @@ def main():
                      "mfma_utilisation": measured_mfma_utilisation(dom, K),     # PMC pass of this build, else null
                      "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern_ms[dom],
                      "empty_event_bracket_ms": timer.empty_bracket_ms(),
+                     # informational: what a cold read + write stream of the synth's image bytes reaches on this pool, whatever its
+                     # access pattern — a flat grid-stride copy included (tools/exp/stream_patterns.hip, profiles/r04_stream_patterns.md)
+                     "measured_copy_ceiling_GBps": 5100.0,
                      # informational: the same with the cost of an empty event bracket taken off (this is the figure that
                      # agrees with rocprofv3's kernel duration to ~1 %, profiles/README.md); `achieved`/`frac` stay raw
                      "frac_minus_empty_bracket": alg[dom] / (max(kern_ms[dom] - timer.empty_bracket_ms(), 1e-6) * 1e-3) / 1e9
