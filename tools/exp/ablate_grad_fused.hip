@@ -8,7 +8,7 @@
 #include <cstring>
 #include <vector>
 
-enum { NO_GV_MFMA = 1, NO_GV_READS = 2, NO_GD_MFMA = 4, NO_GD_READS = 8, NO_IMG_WRITE = 16, NO_G_LOAD = 32, NO_D_STORE = 64,
+enum { NO_FLIP = 1024, NO_GV_MFMA = 1, NO_GV_READS = 2, NO_GD_MFMA = 4, NO_GD_READS = 8, NO_IMG_WRITE = 16, NO_G_LOAD = 32, NO_D_STORE = 64,
        NO_RED = 128, NO_D_TILE = 256, NO_BARRIERS = 512 };
 
 template <int ABL>
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(512) void ablate_kernel(const bf16_t* __restrict__ 
         if (range >= nranges) return;
         k0 = half ? k_split : 0;
         kn = half ? K - k_split : k_split;
-        flip = half ^ (range & 1);
+        flip = (ABL & NO_FLIP) ? 0 : (half ^ (range & 1));
     }
     using T = bf16_t;
     using M = Mma<T>;
@@ -238,6 +238,8 @@ int main(int argc, char** argv) {
         printf("| variant | time |\n|---|---|\n");
         for (int pass = 0; pass < 2; ++pass) {
             run<0>(c, "the kernel as it is", rep);
+            if (c.k_split) run<NO_FLIP>(c, "both halves of a pair walk their tiles in the SAME order", rep);
+            if (c.k_split) run<NO_FLIP | NO_GV_MFMA | NO_GV_READS | NO_GD_MFMA | NO_GD_READS | NO_RED>(c, "the same, stream only", rep);
             run<NO_GV_MFMA | NO_GV_READS>(c, "without grad_v (MFMAs and LDS fragment reads)", rep);
             run<NO_GD_MFMA | NO_GD_READS>(c, "without grad_d's MFMAs and transposing reads", rep);
             run<NO_RED>(c, "without the exchange of the row-split partials through LDS", rep);
