@@ -56,7 +56,7 @@ class classifier_batch_bucket:
 
     Why: on this stack MIOpen goes through its find / compile step for every convolution configuration it has not
     seen, i.e. for every NEW batch size: 0.6-1.0 s (MobileNetV2, fp32) to 2.2-3.2 s (ResNet-50, bf16) for the first
-    forward + backward at a size against 5-8 ms afterwards (tools/exp_ragged_batches.py, DESIGN finding 23) — and
+    forward + backward at a size against 5-8 ms afterwards (tools/exp_ragged_batches.py, FINDINGS.md 23) — and
     performance.py's correctly-classified filter (performance.py:163-165) hands the attack a different number of
     images per batch.  The attack's own arithmetic is untouched: the loss, its mean, the stop test and every ADiL
     kernel see the real rows only; an eval-mode classifier treats the rows of a batch independently.
