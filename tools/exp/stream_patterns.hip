@@ -116,6 +116,39 @@ int main(int argc, char** argv) {
         printf("| %-58s | %7.1f us | %5.2f TB/s |\n", name, us, 2.0 * bytes / (us * 1e-6) / 1e12);
         fflush(stdout);
     };
+    if (argc > 3) {
+        // does the RELATIVE placement of the output batch matter (DRAM bank / channel interleaving of a read stream and a write
+        // stream that advance together)?  One arena per pair; out = x + bytes + delta.
+        for (int i = 0; i < NBUF; ++i) { CK(hipFree(xs[i])); CK(hipFree(os[i])); }
+        const size_t slack = 64u << 20;
+        std::vector<char*> arena(NBUF);
+        for (int i = 0; i < NBUF; ++i) { CK(hipMalloc(&arena[i], 2 * bytes + slack)); CK(hipMemset(arena[i], 0x3c, 2 * bytes + slack)); }
+        printf("| out = x + %zu B + delta | synth pattern (v0) | flat copy |\n|---|---|---|\n", bytes);
+        const size_t deltas[] = {0, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576,
+                                 2097152, 4194304, 8388608, 16777216, 33554432};
+        for (size_t dl : deltas) {
+            double us[2];
+            for (int k = 0; k < 2; ++k) {
+                auto launch = [&](int i) {
+                    const bf16_t* x = (const bf16_t*)arena[i];
+                    bf16_t* o = (bf16_t*)(arena[i] + bytes + dl);
+                    if (k == 0) hipLaunchKernelGGL((sweep<8, 32>), dim3(P / 128, 1), dim3(256), lds, 0, x, o, B, P, B);
+                    else hipLaunchKernelGGL(linear, dim3(2048), dim3(256), 0, 0, (const u32x4*)x, (u32x4*)o, n / 8);
+                };
+                for (int i = 0; i < NBUF; ++i) launch(i);
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < REP; ++i) launch(i % NBUF);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                us[k] = ms * 1e3 / REP;
+            }
+            printf("| %9zu | %6.1f us = %4.2f TB/s | %6.1f us = %4.2f TB/s |\n", dl, us[0], 2.0 * bytes / us[0] / 1e6, us[1], 2.0 * bytes / us[1] / 1e6);
+            fflush(stdout);
+        }
+        return 0;
+    }
     printf("| pattern (B = %d x P = 150528 bf16, out = x + 1, %.0f MB in + %.0f MB out) | time | bytes / time |\n|---|---|---|\n", B, bytes / 1e6, bytes / 1e6);
     for (int pass = 0; pass < 2; ++pass) {
         run("v0  8 B/lane, 256 B rows, 2 rows/instr, tile 128 (now)", [&](int i) {
