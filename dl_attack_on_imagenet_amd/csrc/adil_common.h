@@ -92,7 +92,7 @@ __device__ __forceinline__ float adamw_elem(float p, float g, float& m, float& s
 // the stand-alone reduce kernel and the consumers that fold the reduction into their own launch (adamw_l1ball,
 // pack_codes), so both routes give identical bits.  p = address of the entry in slab 0, stride = floats per slab.
 // 32 independent loads are in flight per lane; the tail uses clamped addresses and 0/1 weights, never a branch around
-// a load (hipcc would serialise them, DESIGN finding 2).
+// a load (hipcc would serialise them, FINDINGS.md 2).
 // --------------------------------------------------------------------------- //
 __device__ __forceinline__ float slab_sum(const float* __restrict__ p, int nslabs, size_t stride) {
     float acc[32];

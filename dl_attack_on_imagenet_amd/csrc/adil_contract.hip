@@ -1126,23 +1126,22 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
     // grad_d and of the range's slab: D, grad_d and the slabs move once.  The halves of a range sit 8 block ids apart,
     // i.e. on the same XCD under the round-robin placement (speed only: the second reader of a g tile then finds it in
     // that XCD's L2 instead of fetching it from HBM again).
-    int range = blockIdx.x, k0 = 0, kn = K, flip = 0;
+    int range = blockIdx.x, k0 = 0, kn = K;
     if (k_split > 0) {
         const int bid = blockIdx.x, half = (bid >> 3) & 1;
         range = (bid >> 4) * 8 + (bid & 7);
         if (range >= nranges) return;                             // whole workgroup, before any barrier
         k0 = half ? k_split : 0;
         kn = half ? K - k_split : k_split;
-        // The two halves of a range walk its tiles in orders that differ by a swap of neighbours (0 1 2 3 ... against
-        // 1 0 3 2 ...): at every step they fetch DIFFERENT tiles of g, and the tile one of them needs next is the one its
-        // partner brought into the XCD's L2 a step earlier.  Walking in the same order, both waited for the same HBM
-        // round trip at every step (the loop is one tile deep: its pace is the load latency) and the pair took as long
-        // as two separate passes over g.  Odd / even ranges start on opposite phases, so that at any moment half of the
-        // pairs are on their HBM step and half on their L2 step.
-        flip = half ^ (range & 1);
+        // Both halves of a range walk its tiles in the SAME order: the second request for a g line then meets the first one
+        // still in flight or fresh in the XCD's L2, and the two 200-byte halves of a grad_d row reach the L2 close enough
+        // together to leave it as whole lines.  Counter traffic at 512 x 150528, K = 100: 301 MB = 1.10x algorithmic.  (Orders
+        // that differ by a swap of neighbours — the halves then never wait for the same HBM round trip — were tried first and
+        // measured 341 MB = 1.25x: a quarter of the second reads missed, and 15 MB of half-written lines were evicted and
+        // fetched back; 3 % slower.  tools/exp/ablate_grad_fused.hip, profiles/r04_grad_fused_ablation.md.)
     }
     // WV = false: the grad_d half alone (no D tile, no grad_v accumulators, no slab) — the LDS-staged grad_d kernel of
-    // K > 64, where the direct-load kernel is left with 128-byte row pieces (finding 17) and the fused kernel with 256 rows.
+    // K > 64, where the direct-load kernel is left with 128-byte row pieces (FINDINGS.md 17) and the fused kernel with 256 rows.
     // NW waves, each owning RB consecutive 32-row batch blocks (RB = 2 keeps the 512-row workgroup at 8 waves, i.e.
     // a 256-register budget per wave: with 16 waves the 128-register cap spills, and a scratch reload behind the
     // prefetched loads drains vmcnt and serialises the stream).
@@ -1170,8 +1169,8 @@ __global__ __launch_bounds__(NW * 64) void grad_fused_mfma_kernel(const T* __res
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int t0 = tile_begin + range * tiles_per_wg;
     const int t1 = min(tile_end, t0 + tiles_per_wg);
-    const int nt = t1 - t0;                                      // tiles of this range, visited in the order tile_at(0), tile_at(1), ...
-    auto tile_at = [&](int i) __attribute__((always_inline)) { const int j = i ^ flip; return t0 + (j < nt ? j : i); };
+    const int nt = t1 - t0;                                      // tiles of this range
+    auto tile_at = [&](int i) __attribute__((always_inline)) { return t0 + i; };
     const int ti = w % NTILE, ks = w / NTILE, tp = ti & 1, ta = ti >> 1;
 
     f32x16 accv[WV ? RB : 1][WV ? AT : 1];

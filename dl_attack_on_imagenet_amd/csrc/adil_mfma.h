@@ -19,7 +19,7 @@ __device__ __forceinline__ void mma16(f32x16& acc, const bf16x8& a, const bf16x8
 }
 __device__ __forceinline__ void lds_sync() { __syncthreads(); }
 // Workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() carries a fence that hipcc
-// lowers to s_waitcnt vmcnt(0), which drains every prefetched tile at every barrier (DESIGN.md finding 3a).
+// lowers to s_waitcnt vmcnt(0), which drains every prefetched tile at every barrier (FINDINGS.md 3a).
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
