@@ -2770,16 +2770,25 @@ static int launch_zstep_range(float* z, float* m, float* sq, const float* d, con
 static inline bool zstep_codes_shape_ok(int B, int P, int K) {
     return B > 0 && K > 0 && round_up(K, 16) <= 112 && P > 0 && P % SYNTH_TILE == 0 && P <= (1 << 23);
 }
-static inline void zstep_codes_grid(int P, int* nslices, int* spw, int* nwg) {
+// rows one workgroup owns: 8 waves x RB blocks of 32 (RB = 2 while the accumulators of two blocks fit: K <= 64 and a batch
+// that fills the second block); the row ranges beyond that go to blockIdx.y
+static inline int zstep_codes_row_blocks(int B, int K) { return (atom_tiles(K) <= 2 && round_up(B, 32) > 256) ? 2 : 1; }
+// One workgroup per CU: the pixel slices are cut into as many ranges as there are CUs PER ROW RANGE, so that the whole grid
+// (ranges x row ranges) is resident at once — and a batch with ny row ranges leaves ny times fewer slabs (one per pixel
+// range, all rows): at 512 x 100 atoms 118 ranges x 2 instead of 236 x 2 workgroups in two rounds, 24 MB of slabs instead of 48.
+static inline void zstep_codes_grid(int B, int P, int K, int* nslices, int* spw, int* nwg, int* ny) {
+    const int rows_per_wg = 8 * zstep_codes_row_blocks(B, K) * 32;
+    *ny = (round_up(B, 32) + rows_per_wg - 1) / rows_per_wg;
+    const int ranges = num_cu() / *ny > 0 ? num_cu() / *ny : 1;
     *nslices = P / SYNTH_TILE;
-    *spw = (*nslices + num_cu() - 1) / num_cu();
+    *spw = (*nslices + ranges - 1) / ranges;
     *nwg = (*nslices + *spw - 1) / *spw;
 }
 
 extern "C" size_t adil_zstep_codes_slab_bytes(int B, int P, int K) {
     if (!zstep_codes_shape_ok(B, P, K)) return 0;
-    int nslices, spw, nwg;
-    zstep_codes_grid(P, &nslices, &spw, &nwg);
+    int nslices, spw, nwg, ny;
+    zstep_codes_grid(B, P, K, &nslices, &spw, &nwg, &ny);
     return (size_t)nwg * round_up(B, 32) * K * sizeof(float);
 }
 
@@ -2788,12 +2797,12 @@ static int launch_zstep_codes(float* z, float* m, float* sq, const float* d, con
                               AdamWHyper hy, float lo, float hi, float* max_abs_delta, const float* skip_if_below,
                               float skip_threshold, float* clear, const float* dyn, int* nslabs_out, hipStream_t st) {
     const int Kp = round_up(K, 16), Bp = round_up(B, 32);
-    int nslices, spw, nwg;
-    zstep_codes_grid(P, &nslices, &spw, &nwg);
+    int nslices, spw, nwg, ny;
+    zstep_codes_grid(B, P, K, &nslices, &spw, &nwg, &ny);
+    if (RB != zstep_codes_row_blocks(B, K)) return ADIL_EINVAL;          // the grid above was cut for another instantiation
     const size_t lds = (size_t)3 * SYNTH_TILE * ZCodes<AT>::KS * sizeof(bf16_t) + (size_t)8 * 16 * ZC_IS * sizeof(float);
     int rc = set_lds((const void*)zstep_codes_kernel<AT, RB>, lds);
     if (rc) return rc;
-    const int rows_per_wg = 8 * RB * 32, ny = (Bp + rows_per_wg - 1) / rows_per_wg;
     hipLaunchKernelGGL((zstep_codes_kernel<AT, RB>), dim3(nwg, ny), dim3(512), lds, st, z, m, sq, d, vp, slab, B, Bp, P, K, Kp, hy,
                        lo, hi, max_abs_delta, nslices, spw, skip_if_below, skip_threshold, clear, dyn);
     ADIL_CHECK_LAUNCH();
